@@ -1,0 +1,194 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of the C oracle (oracle/vsp_ref.c).
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product.
+All arrays are numpy uint64, canonical little-endian limbs (Fr 4, G1 12, G2 24 per element).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "build", "libvsp_ref.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.ref_init()
+    lib.ref_r1cs_synth.restype = C.c_void_p
+    lib.ref_r1cs_from_csr.restype = C.c_void_p
+    lib.ref_groth16_generate.restype = C.c_void_p
+    lib.ref_r1cs_num_vars.restype = C.c_size_t
+    lib.ref_r1cs_nnz.restype = C.c_size_t
+    lib.ref_keypair_count.restype = C.c_size_t
+    lib.ref_r1cs_domain_log.restype = C.c_uint
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def fp_mul(a, b):
+    out = np.zeros(6, np.uint64); lib().ref_fp_mul(_p(_u64(a)), _p(_u64(b)), _p(out)); return out
+
+
+def fp_inv(a):
+    out = np.zeros(6, np.uint64); lib().ref_fp_inv(_p(_u64(a)), _p(out)); return out
+
+
+def fr_mul(a, b):
+    out = np.zeros(4, np.uint64); lib().ref_fr_mul(_p(_u64(a)), _p(_u64(b)), _p(out)); return out
+
+
+def fr_inv(a):
+    out = np.zeros(4, np.uint64); lib().ref_fr_inv(_p(_u64(a)), _p(out)); return out
+
+
+def g1_add(p, q):
+    out = np.zeros(12, np.uint64); lib().ref_g1_add(_p(_u64(p)), _p(_u64(q)), _p(out)); return out
+
+
+def g1_mul(p, k):
+    out = np.zeros(12, np.uint64); lib().ref_g1_mul(_p(_u64(p)), _p(_u64(k)), _p(out)); return out
+
+
+def g2_add(p, q):
+    out = np.zeros(24, np.uint64); lib().ref_g2_add(_p(_u64(p)), _p(_u64(q)), _p(out)); return out
+
+
+def g2_mul(p, k):
+    out = np.zeros(24, np.uint64); lib().ref_g2_mul(_p(_u64(p)), _p(_u64(k)), _p(out)); return out
+
+
+def msm_g1(bases, scalars, mixed=False):
+    bases, scalars = _u64(bases), _u64(scalars)
+    n = scalars.size // 4
+    out = np.zeros(12, np.uint64)
+    lib().ref_msm_g1(_p(bases), _p(scalars), C.c_size_t(n), _p(out), C.c_int(int(mixed)))
+    return out
+
+
+def msm_g2(bases, scalars, mixed=False):
+    bases, scalars = _u64(bases), _u64(scalars)
+    n = scalars.size // 4
+    out = np.zeros(24, np.uint64)
+    lib().ref_msm_g2(_p(bases), _p(scalars), C.c_size_t(n), _p(out), C.c_int(int(mixed)))
+    return out
+
+
+def g1_batch_mul_gen(scalars):
+    scalars = _u64(scalars); n = scalars.size // 4
+    out = np.zeros((n, 12), np.uint64); lib().ref_g1_batch_mul_gen(_p(scalars), C.c_size_t(n), _p(out)); return out
+
+
+def g2_batch_mul_gen(scalars):
+    scalars = _u64(scalars); n = scalars.size // 4
+    out = np.zeros((n, 24), np.uint64); lib().ref_g2_batch_mul_gen(_p(scalars), C.c_size_t(n), _p(out)); return out
+
+
+def ntt_fr(a, inverse=False, coset=None):
+    a = _u64(a).copy().reshape(-1, 4)
+    n = a.shape[0]; log_m = n.bit_length() - 1
+    assert 1 << log_m == n
+    g = None if coset is None else _u64(coset)
+    lib().ref_ntt_fr(_p(a), C.c_uint(log_m), C.c_int(int(inverse)), _p(g))
+    return a
+
+
+class R1CS:
+    """Handle on a C-side constraint system (CSR triples A, B, C)."""
+
+    def __init__(self, handle, num_constraints, num_inputs):
+        self.h = C.c_void_p(handle)
+        self.num_constraints, self.num_inputs = num_constraints, num_inputs
+        self.num_vars = lib().ref_r1cs_num_vars(self.h)
+        self.log_m = lib().ref_r1cs_domain_log(self.h)
+
+    @classmethod
+    def synth(cls, num_constraints, num_inputs, seed):
+        nv = num_constraints + num_inputs
+        wit = np.zeros((nv, 4), np.uint64)
+        h = lib().ref_r1cs_synth(C.c_size_t(num_constraints), C.c_size_t(num_inputs), C.c_uint64(seed), _p(wit))
+        cs = cls(h, num_constraints, num_inputs)
+        return cs, wit
+
+    def export(self):
+        """-> [(row_ptr u32[nc+1], col_idx u32[nnz], coeff u64[nnz,4])] for A, B, C."""
+        out = []
+        for m in range(3):
+            nnz = lib().ref_r1cs_nnz(self.h, C.c_int(m))
+            rp = np.zeros(self.num_constraints + 1, np.uint32)
+            ci = np.zeros(max(nnz, 1), np.uint32)
+            co = np.zeros((max(nnz, 1), 4), np.uint64)
+            lib().ref_r1cs_export(self.h, C.c_int(m), _p(rp), _p(ci), _p(co))
+            out.append((rp, ci[:nnz], co[:nnz]))
+        return out
+
+    def is_satisfied(self, witness):
+        return bool(lib().ref_r1cs_is_satisfied(self.h, _p(_u64(witness))))
+
+    def witness_map(self, witness, want_abc=False):
+        m = 1 << self.log_m
+        H = np.zeros((m, 4), np.uint64)
+        if want_abc:
+            Az, Bz, Cz = (np.zeros((m, 4), np.uint64) for _ in range(3))
+            lib().ref_witness_map(self.h, _p(_u64(witness)), _p(H), _p(Az), _p(Bz), _p(Cz))
+            return H, Az, Bz, Cz
+        lib().ref_witness_map(self.h, _p(_u64(witness)), _p(H), None, None, None)
+        return H
+
+    def free(self):
+        if self.h:
+            lib().ref_r1cs_free(self.h); self.h = None
+
+
+KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "H_query": (3, 12),
+             "L_query": (4, 12), "gamma_ABC_g1": (5, 12), "alpha_g1": (6, 12), "beta_g1": (7, 12),
+             "delta_g1": (8, 12), "beta_g2": (9, 24), "delta_g2": (10, 24), "gamma_g2": (11, 24)}
+
+
+class Keypair:
+    def __init__(self, cs, toxic):
+        """toxic: uint64[5,4] = (t, alpha, beta, gamma, delta), canonical Fr."""
+        self.cs = cs
+        self.h = C.c_void_p(lib().ref_groth16_generate(cs.h, _p(_u64(toxic))))
+
+    def part(self, name):
+        which, width = KEY_PARTS[name]
+        n = lib().ref_keypair_count(self.h, C.c_int(which))
+        out = np.zeros((n, width), np.uint64)
+        lib().ref_keypair_export(self.h, C.c_int(which), _p(out))
+        return out
+
+    def prove(self, witness, r, s, P1=None, r_enc=None):
+        A = np.zeros(12, np.uint64); B = np.zeros(24, np.uint64); Cc = np.zeros(12, np.uint64)
+        lib().ref_groth16_prove(self.cs.h, self.h, _p(_u64(witness)), _p(_u64(r)), _p(_u64(s)),
+                                _p(None if P1 is None else _u64(P1)), _p(None if r_enc is None else _u64(r_enc)),
+                                _p(A), _p(B), _p(Cc))
+        return A, B, Cc
+
+    def free(self):
+        if self.h:
+            lib().ref_keypair_free(self.h); self.h = None
