@@ -1,0 +1,155 @@
+/* vsp.h -- C ABI of the MI355X-native Groth16 prover hot path (libvsp_hip.so).
+ *
+ * Drop-in boundary for the one compute-heavy path of NilFoundation/vote-saver-protocol: the
+ * r1cs_gg_ppzksnark prover that runs below
+ *     bin/cli/include/nil/vote_saver/common.hpp:1132-1135   (encrypt<elgamal_verifiable<bls12_381>, ...>)
+ * whose two hot loops are crypto3-algebra `multiexp` (included via common.hpp:38) and crypto3-math
+ * `evaluation_domain` (absent submodules, .gitmodules:8-9,47-48).  The reference has no FFI for
+ * this path (header-only C++ templates); its only C ABI convention is the WASM shell
+ * (bin/cli/src/wasm.cpp:32-44,62-201): POD pointer+size buffers, blocking calls.  This header keeps
+ * that convention, with two deliberate differences: every buffer is CALLER-owned,
+ * and failures are returned as negative status codes instead of aborting the process
+ * (reference: BOOST_ASSERT -> std::exit(1), bin/cli/src/main.cpp:24-33).
+ *
+ * Data layout at the boundary (host or device memory, see each function):
+ *   Fr scalar        4 x uint64  canonical (non-Montgomery) little-endian limbs, value < r
+ *   Fp element       6 x uint64  canonical little-endian limbs, value < p
+ *   G1 affine point 12 x uint64  x, y                      -- infinity = all 96 bytes zero
+ *   G2 affine point 24 x uint64  x.c0, x.c1, y.c0, y.c1    -- infinity = all 192 bytes zero
+ *   G1 Jacobian     18 x uint64  X, Y, Z (x = X/Z^2, y = Y/Z^3; Z = 0 infinity); G2: 36 x uint64
+ * No torch types, no C++ types: plain pointers and sizes.
+ *
+ * Threading: a vsp_ctx is used by one thread at a time (the reference is single-threaded,
+ * bin/cli/CMakeLists.txt:114-116); different contexts are independent.  All calls block until the
+ * result is in the caller's buffer unless the name ends in _async.
+ */
+#ifndef VSP_H
+#define VSP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsp_ctx vsp_ctx;
+typedef struct vsp_bases vsp_bases;     /* device-resident MSM bases (a slice of the proving key) */
+typedef struct vsp_r1cs vsp_r1cs;       /* device-resident constraint system (three CSR matrices) */
+typedef struct vsp_pk vsp_pk;           /* device-resident Groth16 proving key */
+
+enum {
+    VSP_OK = 0,
+    VSP_ERR_ARG = -1,        /* null pointer, size out of range, scalar/coordinate layout violated */
+    VSP_ERR_HIP = -2,        /* a HIP runtime call failed; vsp_last_error() has the text */
+    VSP_ERR_NOMEM = -3,
+    VSP_ERR_UNSUPPORTED = -4 /* e.g. log_m > 28 */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* One context = one GPU (device_ordinal) + one HIP stream + grow-only device workspaces. */
+vsp_ctx *vsp_create(int device_ordinal);
+void vsp_destroy(vsp_ctx *ctx);
+const char *vsp_last_error(vsp_ctx *ctx);
+/* Run on a caller-provided hipStream_t (e.g. torch.cuda.Stream().cuda_stream); NULL = context's own. */
+int vsp_set_stream(vsp_ctx *ctx, void *hip_stream);
+int vsp_synchronize(vsp_ctx *ctx);
+/* Named timing/diagnostic values of the last calls, e.g. "msm_accum_ms" (HIP-event time of the bucket
+ * accumulation kernel, summed since the last vsp_stats_reset), "msm_accum_launches", "msm_window_bits". */
+double vsp_get_stat(vsp_ctx *ctx, const char *name);
+void vsp_stats_reset(vsp_ctx *ctx);
+/* tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold) */
+int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
+
+/* ---- raw device memory helpers (for callers without torch) --------------------------------- */
+void *vsp_dmalloc(vsp_ctx *ctx, size_t bytes);
+void vsp_dfree(vsp_ctx *ctx, void *dptr);
+int vsp_h2d(vsp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int vsp_d2h(vsp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- multi-scalar multiplication: algebra::multiexp<multiexp_method_BDLO12> (a1), ------------
+ *      multiexp_with_mixed_addition (a2: zero scalars are skipped, equal-to-one scalars are summed
+ *      directly -- both happen inside the same bucket pipeline), G2 half of kc_multiexp (a3).
+ * result = sum_i scalars[i] * bases[i], returned as an affine point (out_is_inf = 1 for infinity). */
+int vsp_msm_g1(vsp_ctx *ctx, const uint64_t *bases /* host n x 12 */, const uint64_t *scalars /* host n x 4 */,
+               size_t n, uint64_t out_affine[12], int *out_is_inf);
+int vsp_msm_g2(vsp_ctx *ctx, const uint64_t *bases /* host n x 24 */, const uint64_t *scalars /* host n x 4 */,
+               size_t n, uint64_t out_affine[24], int *out_is_inf);
+
+/* Resident bases (proving-key slices, a9): uploaded and converted once, reused by every proof. */
+vsp_bases *vsp_bases_upload_g1(vsp_ctx *ctx, const uint64_t *bases /* host n x 12 */, size_t n);
+vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases /* host n x 24 */, size_t n);
+/* bases already in device memory (same canonical layout), e.g. produced by vsp_fixed_base_mul_* */
+vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n);
+vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n);
+size_t vsp_bases_count(const vsp_bases *b);
+void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b);
+
+/* MSM over resident bases [first, first+n) with scalars in DEVICE memory (n x 4 uint64, canonical).
+ * out_affine is a host buffer (12 or 24 uint64 according to the group of `bases`). */
+int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n,
+                     const void *d_scalars, uint64_t *out_affine, int *out_is_inf);
+/* Same, but the result is left as a Jacobian partial sum (X, Y, Z canonical: 18 / 36 uint64) in the host
+ * buffer -- the fixed-size record ranks exchange in the sharded multi-GPU MSM. */
+int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n,
+                              const void *d_scalars, uint64_t *out_jacobian);
+/* Fold `count` Jacobian records (host, canonical) into one affine point; group: 1 = G1, 2 = G2. */
+int vsp_fold_jacobian(vsp_ctx *ctx, int group, const uint64_t *records, size_t count,
+                      uint64_t *out_affine, int *out_is_inf);
+
+/* ---- evaluation_domain<Fr> (a6): basic radix-2 domain of size m = 2^log_m ------------------
+ * In-place on n = 2^log_m canonical Fr values.
+ *   inverse = 0, coset_g = NULL : fft          a[k] <- sum_j a[j] w^(jk),  w = 7^((r-1)/2^32)^(2^(32-log_m))
+ *   inverse = 1, coset_g = NULL : inverse_fft  (w^-1, then scale by m^-1)
+ *   inverse = 0, coset_g = g    : coset fft    (a[j] *= g^j first)
+ *   inverse = 1, coset_g = g    : inverse coset fft (inverse_fft, then a[j] *= g^-j) */
+int vsp_ntt_fr(vsp_ctx *ctx, uint64_t *a /* host m x 4 */, unsigned log_m, int inverse, const uint64_t coset_g[4]);
+int vsp_ntt_fr_device(vsp_ctx *ctx, void *d_a /* device m x 4 */, unsigned log_m, int inverse, const uint64_t coset_g[4]);
+
+/* ---- r1cs_to_qap::witness_map (a7) -----------------------------------------------------------
+ * From the three evaluation vectors Az, Bz, Cz over the domain (each m x 4, canonical, zero padded; the
+ * caller has already placed the "input_i * 0 = 0" rows in Az) compute the m coefficients of
+ * H = (A*B - C)/Z  (d1 = d2 = d3 = 0, as the r1cs_gg_ppzksnark prover calls it).  Inputs are overwritten. */
+int vsp_witness_map_h(vsp_ctx *ctx, uint64_t *Az, uint64_t *Bz, uint64_t *Cz /* host */, unsigned log_m,
+                      uint64_t *H /* host m x 4 */);
+int vsp_witness_map_h_device(vsp_ctx *ctx, void *d_Az, void *d_Bz, void *d_Cz, unsigned log_m, void *d_H);
+
+/* ---- constraint system + proving key + prover (a8, a9) -------------------------------------- */
+/* Three CSR matrices over columns 0..num_vars (column 0 is the constant 1); coefficients canonical Fr. */
+vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_inputs, size_t num_vars,
+                          const uint32_t *row_ptr_a, const uint32_t *col_a, const uint64_t *coef_a,
+                          const uint32_t *row_ptr_b, const uint32_t *col_b, const uint64_t *coef_b,
+                          const uint32_t *row_ptr_c, const uint32_t *col_c, const uint64_t *coef_c);
+void vsp_r1cs_free(vsp_ctx *ctx, vsp_r1cs *cs);
+
+/* Proving key = { alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, A_query[num_vars+1],
+ * B_query (G2 and G1 halves, num_vars+1 each), H_query[m-1], L_query[num_vars-num_inputs] }
+ * (proof_system::proving_key_type, common.hpp:173,749-754).  Query handles stay owned by the caller. */
+vsp_pk *vsp_pk_create(vsp_ctx *ctx, const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                      const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                      const vsp_bases *A_query, const vsp_bases *B_query_g1, const vsp_bases *B_query_g2,
+                      const vsp_bases *H_query, const vsp_bases *L_query);
+void vsp_pk_free(vsp_ctx *ctx, vsp_pk *pk);
+
+/* r1cs_gg_ppzksnark_prover::process with explicit randomness r, s (upstream draws them from a
+ * non-seedable device, common.hpp:1131).  witness = primary || auxiliary, num_vars x 4 canonical (host).
+ * If saver_P1 != NULL, r_enc * P1 is added to C (encrypted-input / SAVER mode).
+ * Outputs: affine A (G1), B (G2), C (G1) canonical, and the 192-byte ZCash-compressed proof A||B||C
+ * (the format of the reference's bin/cli/src/data.bin[0:192]); any output pointer may be NULL. */
+int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
+                      const uint64_t r[4], const uint64_t s[4],
+                      const uint64_t *saver_P1 /* 12 or NULL */, const uint64_t *saver_r_enc /* 4 or NULL */,
+                      uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
+
+/* ---- generator-side batch exponentiation (section 8(f).1; also builds synthetic benchmark bases) ---
+ * out[i] = scalars[i] * generator, written to DEVICE memory as canonical affine points. */
+int vsp_fixed_base_mul_g1(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out /* n x 12 u64 */);
+int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out /* n x 24 u64 */);
+
+/* ---- wire format helpers (host only, tiny) --------------------------------------------------- */
+int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]);
+int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSP_H */

@@ -1,0 +1,67 @@
+"""CPU tests of the drop-in boundary: libvsp_hip.so loads without a GPU and exports every symbol that
+include/vsp.h declares; host-only entry points work; the product never reaches into oracle/."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bls12_381 as o
+from conftest import GOLDEN, ROOT, g1_limbs, g2_limbs
+
+import vote_saver_protocol_amd as v
+from vote_saver_protocol_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vsp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = v.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vsp.h but not exported"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(_lib.PROTOTYPES) == names
+
+
+def test_compress_matches_reference_data_bin():
+    """vsp_g1_compress / vsp_g2_compress (host-only) reproduce the bytes of reference data.bin[0:192]."""
+    d = bytes.fromhex(open(os.path.join(GOLDEN, "data_bin_proof.hex")).read().strip())
+    A = o.g1_decompress(d[0:48]); B = o.g2_decompress(d[48:144]); Cc = o.g1_decompress(d[144:192])
+    assert v.g1_compress(g1_limbs(A)) == d[0:48]
+    assert v.g2_compress(g2_limbs(B)) == d[48:144]
+    assert v.g1_compress(g1_limbs(Cc)) == d[144:192]
+    assert v.g1_compress(np.zeros(12, np.uint64)) == o.g1_compress(None)
+    assert v.g2_compress(np.zeros(24, np.uint64)) == o.g2_compress(None)
+    for k in (1, 2, 12345):
+        P = o.G1.mul(o.G1.gen, k); Q = o.G2.mul(o.G2.gen, k)
+        assert v.g1_compress(g1_limbs(P)) == o.g1_compress(P)
+        assert v.g2_compress(g2_limbs(Q)) == o.g2_compress(Q)
+        assert v.g1_compress(g1_limbs(o.G1.neg(P))) == o.g1_compress(o.G1.neg(P))
+        assert v.g2_compress(g2_limbs(o.G2.neg(Q))) == o.g2_compress(o.G2.neg(Q))
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a HIP device the product must fail loudly, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(v.VspError):
+        v.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vote_saver_protocol_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in text and "import cref" not in text and "bls12_381" not in text.replace("BLS12-381", ""), (dirpath, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        text = open(os.path.join(ROOT, "include", f), errors="ignore").read() if os.path.isfile(os.path.join(ROOT, "include", f)) else ""
+        assert "vsp_ref" not in text

@@ -1,0 +1,167 @@
+"""GPU parity: vsp_msm_g1 / vsp_msm_g2 / resident-bases MSM (HIP) vs the oracle -- identical affine points.
+Edge cases follow what multiexp's callers can feed it: empty input, single point, zero / one / r-1 scalars,
+duplicate bases, cancelling pairs, infinity bases, the 0/1-heavy witness distribution of
+multiexp_with_mixed_addition, every-scalar-equal (one bucket per window)."""
+import numpy as np
+import pytest
+
+import bls12_381 as o
+from conftest import I, L, dec1, dec2, fr_array, fr_ints_fast, g1_limbs, g2_limbs, load_golden, rand_fr_array
+
+import vote_saver_protocol_amd as v
+
+pytestmark = pytest.mark.gpu
+
+
+def test_msm_golden_vectors(ctx):
+    for case in load_golden("msm.json"):
+        scal = fr_array([int(s, 16) for s in case["scalars"]])
+        if case["group"] == "g1":
+            bases = np.stack([g1_limbs(dec1(p)) for p in case["bases"]])
+            assert o.g1_from_limbs(v.multiexp(ctx, bases, scal, 1)) == dec1(case["result"]), case["n"]
+            assert o.g1_from_limbs(v.multiexp_with_mixed_addition(ctx, bases, scal, 1)) == dec1(case["result"])
+        else:
+            bases = np.stack([g2_limbs(dec2(p)) for p in case["bases"]])
+            assert o.g2_from_limbs(v.multiexp(ctx, bases, scal, 2)) == dec2(case["result"]), case["n"]
+
+
+def test_msm_empty_and_degenerate(ctx):
+    assert not v.multiexp(ctx, np.zeros((0, 12), np.uint64), np.zeros((0, 4), np.uint64), 1).any()
+    assert not v.multiexp(ctx, np.zeros((0, 24), np.uint64), np.zeros((0, 4), np.uint64), 2).any()
+    G = g1_limbs(o.G1.gen).reshape(1, 12)
+    assert not v.multiexp(ctx, G, fr_array([0]), 1).any()                      # 0 * G
+    assert o.g1_from_limbs(v.multiexp(ctx, G, fr_array([1]), 1)) == o.G1.gen
+    assert o.g1_from_limbs(v.multiexp(ctx, G, fr_array([o.R - 1]), 1)) == o.G1.neg(o.G1.gen)
+    two = np.concatenate([G, g1_limbs(o.G1.neg(o.G1.gen)).reshape(1, 12)])
+    assert not v.multiexp(ctx, two, fr_array([12345, 12345]), 1).any()          # P - P
+    assert not v.multiexp(ctx, np.zeros((3, 12), np.uint64), fr_array([5, 6, 7]), 1).any()   # all-infinity bases
+    with pytest.raises(ValueError):
+        v.multiexp(ctx, G, fr_array([1, 2]), 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 256, 1000, 4096])
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_vs_c_oracle_random(ctx, cref, n, group):
+    if group == 2 and n > 1000:
+        pytest.skip("G2 oracle time")
+    ks = rand_fr_array(n, seed=7 * n + group)
+    ss = rand_fr_array(n, seed=11 * n + group)
+    bases = cref.g1_batch_mul_gen(ks) if group == 1 else cref.g2_batch_mul_gen(ks)
+    exp = cref.msm_g1(bases, ss) if group == 1 else cref.msm_g2(bases, ss)
+    assert np.array_equal(v.multiexp(ctx, bases, ss, group), exp)
+
+
+@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16])
+def test_msm_every_window_size(ctx, cref, window_bits):
+    n = 700
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=1))
+    ss = rand_fr_array(n, seed=2)
+    ss[0] = L(o.R - 1, 4); ss[1] = L(1, 4); ss[2] = 0
+    exp = cref.msm_g1(bases, ss)
+    ctx.set_option("msm_window_bits", window_bits)
+    try:
+        assert np.array_equal(v.multiexp(ctx, bases, ss, 1), exp)
+        assert ctx.stat("msm_window_bits") == window_bits
+    finally:
+        ctx.set_option("msm_window_bits", 0)
+
+
+@pytest.mark.parametrize("kind", ["all_zero", "all_one", "boolean_90", "all_equal", "small"])
+def test_msm_skewed_scalars(ctx, cref, kind):
+    """the stress variants of SURVEY.md 8(d): heavy buckets are split and merged by workgroups"""
+    n = 6000
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=5))
+    rng = np.random.default_rng(9)
+    ss = np.zeros((n, 4), np.uint64)
+    if kind == "all_one":
+        ss[:, 0] = 1
+    elif kind == "boolean_90":
+        ss = rand_fr_array(n, seed=6)
+        mask = rng.random(n) < 0.9
+        ss[mask] = 0
+        ss[mask, 0] = rng.integers(0, 2, size=int(mask.sum()), dtype=np.uint64)
+    elif kind == "all_equal":
+        ss[:] = rand_fr_array(1, seed=8)[0]
+    elif kind == "small":
+        ss[:, 0] = rng.integers(0, 1000, size=n, dtype=np.uint64)
+    exp = cref.msm_g1(bases, ss, mixed=True)
+    ctx.set_option("msm_split", 64)               # force many bucket parts even at this size
+    try:
+        assert np.array_equal(v.multiexp_with_mixed_addition(ctx, bases, ss, 1), exp)
+    finally:
+        ctx.set_option("msm_split", 0)
+    assert np.array_equal(v.multiexp(ctx, bases, ss, 1), exp)
+
+
+def test_msm_g2_skewed(ctx, cref):
+    n = 900
+    bases = cref.g2_batch_mul_gen(rand_fr_array(n, seed=15))
+    ss = rand_fr_array(n, seed=16)
+    ss[: n // 2] = 0
+    ss[: n // 2, 0] = 1
+    ctx.set_option("msm_split", 32)
+    try:
+        assert np.array_equal(v.multiexp(ctx, bases, ss, 2), cref.msm_g2(bases, ss, mixed=True))
+    finally:
+        ctx.set_option("msm_split", 0)
+
+
+def test_msm_resident_bases_subranges_and_jacobian_fold(ctx, cref):
+    """resident proving-key slices, sub-range MSM, and the Jacobian partial-sum records of the sharded MSM"""
+    n = 3000
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=21))
+    ss = rand_fr_array(n, seed=22)
+    B = ctx.upload_bases(bases, 1)
+    d_s = ctx.to_device(ss)
+    try:
+        full, inf = B.msm(d_s)
+        assert not inf and np.array_equal(full, cref.msm_g1(bases, ss))
+        # shard into 3 uneven chunks, fold the Jacobian records
+        cuts = [0, 1000, 1001, n]
+        recs = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            recs.append(B.msm_jacobian(d_s + 32 * a, n=b - a, first=a))
+            part, _ = B.msm(d_s + 32 * a, n=b - a, first=a)
+            assert np.array_equal(part, cref.msm_g1(bases[a:b], ss[a:b]))
+        assert np.array_equal(v.fold_jacobian(ctx, np.stack(recs), 1), full)
+        with pytest.raises(v.VspError):
+            B.msm(d_s, n=10, first=n - 5)          # range outside the resident bases
+    finally:
+        ctx.dfree(d_s); B.free()
+
+
+def test_fixed_base_mul_vs_oracle(ctx, cref):
+    n = 300
+    ks = rand_fr_array(n, seed=31)
+    ks[0] = 0; ks[1] = L(1, 4); ks[2] = L(o.R - 1, 4)
+    d_k = ctx.to_device(ks)
+    for group, width, ref in ((1, 12, cref.g1_batch_mul_gen), (2, 24, cref.g2_batch_mul_gen)):
+        d_out = v.fixed_base_mul(ctx, d_k, n, group)
+        out = np.zeros((n, width), np.uint64)
+        ctx.d2h(out, d_out)
+        assert np.array_equal(out, ref(ks))
+        ctx.dfree(d_out)
+    ctx.dfree(d_k)
+
+
+def test_msm_full_size_2p20_discrete_log_identity(ctx, cref):
+    """BASELINE config 2 (2^20 points, uniform scalars): bases k_i*G are generated on the GPU, so the MSM must
+    equal (sum k_i s_i mod r) * G -- one scalar multiplication on the oracle side.  Plus a 2^17 slice checked
+    bit for bit against the C oracle's BDLO12."""
+    n = 1 << 20
+    ks = rand_fr_array(n, seed=1)
+    ss = rand_fr_array(n, seed=2)
+    d_k = ctx.to_device(ks); d_s = ctx.to_device(ss)
+    d_b = v.fixed_base_mul(ctx, d_k, n, 1)
+    B = ctx.bases_from_device(d_b, n, 1)
+    try:
+        got, inf = B.msm(d_s)
+        k_int = fr_ints_fast(ks); s_int = fr_ints_fast(ss)
+        e = sum(a * b for a, b in zip(k_int, s_int)) % o.R
+        assert not inf and np.array_equal(got, cref.g1_mul(g1_limbs(o.G1.gen), L(e, 4)))
+        m = 1 << 15
+        host_b = np.zeros((m, 12), np.uint64); ctx.d2h(host_b, d_b + 96 * 777)
+        part, _ = B.msm(d_s + 32 * 777, n=m, first=777)
+        assert np.array_equal(part, cref.msm_g1(host_b, ss[777:777 + m]))
+    finally:
+        B.free(); ctx.dfree(d_b); ctx.dfree(d_k); ctx.dfree(d_s)

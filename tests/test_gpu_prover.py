@@ -1,0 +1,64 @@
+"""GPU parity: vsp_groth16_prove (HIP) vs the C oracle's r1cs_gg_ppzksnark prover on the same R1CS, proving
+key, witness and (r, s) -- identical A, B, C and identical 192 proof bytes -- and the pairing equation."""
+import numpy as np
+import pytest
+
+import bls12_381 as o
+from conftest import I, L, fr_array
+
+import vote_saver_protocol_amd as v
+
+pytestmark = pytest.mark.gpu
+
+
+def build(ctx, cref, nc, ni, seed):
+    gen = o.splitmix64(seed)
+    cs, wit = cref.R1CS.synth(nc, ni, seed)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    kp = cref.Keypair(cs, tox)
+    A, B, Cm = cs.export()
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
+    q = [ctx.upload_bases(kp.part(n), g) for n, g in (("A_query", 1), ("B_query_g1", 1), ("B_query_g2", 2), ("H_query", 1), ("L_query", 1))]
+    pk = v.ProvingKey(ctx, kp.part("alpha_g1")[0], kp.part("beta_g1")[0], kp.part("beta_g2")[0], kp.part("delta_g1")[0], kp.part("delta_g2")[0], *q)
+    r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
+    return cs, wit, kp, dcs, pk, q, r, s
+
+
+@pytest.mark.parametrize("nc,ni", [(10, 2), (300, 5), (2000, 30)])
+def test_prove_bit_exact_vs_oracle(ctx, cref, nc, ni):
+    cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, nc, ni, seed=nc)
+    A, B, Cc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s)
+    eA, eB, eC = kp.prove(wit, r, s)
+    assert np.array_equal(A, eA) and np.array_equal(B, eB) and np.array_equal(Cc, eC)
+    exp_bytes = o.g1_compress(o.g1_from_limbs(eA)) + o.g2_compress(o.g2_from_limbs(eB)) + o.g1_compress(o.g1_from_limbs(eC))
+    assert proof == exp_bytes and len(proof) == 192
+    # SAVER term r_enc * P1 on C
+    P1 = kp.part("A_query")[3]; renc = L(987654321, 4)
+    A2, B2, C2, _ = v.groth16_prove(ctx, dcs, pk, wit, r, s, saver_P1=P1, saver_r_enc=renc)
+    sA, sB, sC = kp.prove(wit, r, s, P1=P1, r_enc=renc)
+    assert np.array_equal(A2, sA) and np.array_equal(B2, sB) and np.array_equal(C2, sC)
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_gpu_proof_satisfies_pairing_equation(ctx, cref):
+    import pairing as pg
+    cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, 500, 6, seed=77)
+    A, B, Cc, _ = v.groth16_prove(ctx, dcs, pk, wit, r, s)
+    vk = dict(alpha_g1=o.g1_from_limbs(kp.part("alpha_g1")[0]), beta_g2=o.g2_from_limbs(kp.part("beta_g2")[0]),
+              gamma_g2=o.g2_from_limbs(kp.part("gamma_g2")[0]), delta_g2=o.g2_from_limbs(kp.part("delta_g2")[0]),
+              gamma_ABC_g1=[o.g1_from_limbs(x) for x in kp.part("gamma_ABC_g1")])
+    pub = [I(wit[i]) for i in range(6)]
+    assert pg.groth16_verify(vk, pub, (o.g1_from_limbs(A), o.g2_from_limbs(B), o.g1_from_limbs(Cc)))
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_prove_rejects_mismatched_key(ctx, cref):
+    cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, 40, 2, seed=3)
+    cs2, wit2 = cref.R1CS.synth(41, 2, 3)
+    A, B, Cm = cs2.export()
+    dcs2 = v.R1CS(ctx, 41, 2, cs2.num_vars, A, B, Cm)
+    with pytest.raises(v.VspError):
+        v.groth16_prove(ctx, dcs2, pk, wit2, r, s)
+    with pytest.raises(ValueError):
+        v.groth16_prove(ctx, dcs, pk, wit[:-1], r, s)
+    dcs2.free(); cs2.free(); pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

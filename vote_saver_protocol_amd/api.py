@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference's interface for the prover hot path, on top of the C ABI.
+
+The reference exposes this path as C++ templates (absent crypto3 submodules):
+    algebra::multiexp<multiexp_method_BDLO12>(bases_begin, bases_end, scalars_begin, scalars_end, chunks)
+    algebra::multiexp_with_mixed_addition<...>(...)
+    math::make_evaluation_domain<Fr>(m) -> evaluation_domain { m, fft, inverse_fft, ... }
+    zk::snark::r1cs_gg_ppzksnark prover (reached from bin/cli/include/nil/vote_saver/common.hpp:1132-1135)
+This module keeps the same names and argument meaning with numpy arrays of canonical little-endian
+uint64 limbs (Fr: [n,4], G1 affine: [n,12], G2 affine: [n,24]; infinity = all zero).  Every call goes
+through libvsp_hip.so; nothing here computes field or curve arithmetic on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class VspError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):          # torch tensor (device or host memory)
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+def _u64(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+class Context:
+    """One GPU + one HIP stream + grow-only device workspaces (vsp_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.h = self.lib.vsp_create(int(device))
+        if not self.h:
+            raise VspError(f"vsp_create({device}) failed: no such HIP device (this path has no CPU fallback)")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.vsp_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise VspError(f"vsp error {rc}: {self.lib.vsp_last_error(self.h).decode()}")
+
+    def last_error(self):
+        return self.lib.vsp_last_error(self.h).decode()
+
+    def set_stream(self, stream_handle):
+        self.check(self.lib.vsp_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self.check(self.lib.vsp_synchronize(self.h))
+
+    def stat(self, name):
+        return self.lib.vsp_get_stat(self.h, name.encode())
+
+    def stats_reset(self):
+        self.lib.vsp_stats_reset(self.h)
+
+    def set_option(self, name, value):
+        self.check(self.lib.vsp_set_option(self.h, name.encode(), int(value)))
+
+    # ---- raw device memory
+    def dmalloc(self, nbytes):
+        p = self.lib.vsp_dmalloc(self.h, nbytes)
+        if not p:
+            raise VspError("vsp_dmalloc failed: " + self.last_error())
+        return p
+
+    def dfree(self, p):
+        self.lib.vsp_dfree(self.h, C.c_void_p(p))
+
+    def h2d(self, dptr, host):
+        host = np.ascontiguousarray(host)
+        self.check(self.lib.vsp_h2d(self.h, C.c_void_p(dptr), _ptr(host), host.nbytes))
+
+    def d2h(self, host, dptr):
+        self.check(self.lib.vsp_d2h(self.h, _ptr(host), C.c_void_p(dptr), host.nbytes))
+
+    def to_device(self, host):
+        host = np.ascontiguousarray(host)
+        p = self.dmalloc(max(host.nbytes, 16))
+        self.h2d(p, host)
+        return p
+
+    # ---- bases
+    def upload_bases(self, bases, group=1):
+        cols = 12 if group == 1 else 24
+        bases = _u64(bases, cols)
+        fn = self.lib.vsp_bases_upload_g1 if group == 1 else self.lib.vsp_bases_upload_g2
+        h = fn(self.h, _ptr(bases), bases.shape[0])
+        if not h:
+            raise VspError("bases upload failed: " + self.last_error())
+        return Bases(self, h, group)
+
+    def bases_from_device(self, dptr, n, group=1):
+        fn = self.lib.vsp_bases_from_device_g1 if group == 1 else self.lib.vsp_bases_from_device_g2
+        h = fn(self.h, _ptr(dptr), n)
+        if not h:
+            raise VspError("bases_from_device failed: " + self.last_error())
+        return Bases(self, h, group)
+
+
+class Bases:
+    """Device-resident MSM bases (a proving-key query), vsp_bases."""
+
+    def __init__(self, ctx, handle, group):
+        self.ctx, self.h, self.group = ctx, handle, group
+        self.n = ctx.lib.vsp_bases_count(handle)
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_bases_free(self.ctx.h, self.h)
+        self.h = None
+
+    def msm(self, d_scalars, n=None, first=0):
+        """sum_i scalars[i] * bases[first+i]; d_scalars is a device pointer / torch tensor.  -> (affine, is_inf)."""
+        n = self.n - first if n is None else n
+        out = np.zeros(12 if self.group == 1 else 24, np.uint64)
+        inf = C.c_int(0)
+        self.ctx.check(self.ctx.lib.vsp_msm_resident(self.ctx.h, self.h, first, n, _ptr(d_scalars), _ptr(out), C.byref(inf)))
+        return out, bool(inf.value)
+
+    def msm_jacobian(self, d_scalars, n=None, first=0):
+        """Same, result as the Jacobian partial-sum record (18 / 36 uint64) ranks exchange."""
+        n = self.n - first if n is None else n
+        out = np.zeros(18 if self.group == 1 else 36, np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_msm_resident_jacobian(self.ctx.h, self.h, first, n, _ptr(d_scalars), _ptr(out)))
+        return out
+
+
+# ---- multiexp (a1-a3) ------------------------------------------------------------------------
+def multiexp(ctx, bases, scalars, group=1):
+    """algebra::multiexp<multiexp_method_BDLO12>: sum_i scalars[i] * bases[i] as an affine point
+    (zero array = infinity).  bases [n,12|24], scalars [n,4], host arrays."""
+    cols = 12 if group == 1 else 24
+    bases, scalars = _u64(bases, cols), _u64(scalars, 4)
+    if bases.shape[0] != scalars.shape[0]:
+        raise ValueError("multiexp: bases and scalars differ in length")   # the reference asserts equal ranges
+    out = np.zeros(cols, np.uint64)
+    inf = C.c_int(0)
+    fn = ctx.lib.vsp_msm_g1 if group == 1 else ctx.lib.vsp_msm_g2
+    ctx.check(fn(ctx.h, _ptr(bases), _ptr(scalars), bases.shape[0], _ptr(out), C.byref(inf)))
+    return out
+
+
+def multiexp_with_mixed_addition(ctx, bases, scalars, group=1):
+    """algebra::multiexp_with_mixed_addition: same value; the 0 / 1 scalar special cases are handled
+    inside the bucket pipeline (zero digits are skipped, the ones share one bucket)."""
+    return multiexp(ctx, bases, scalars, group)
+
+
+def fold_jacobian(ctx, records, group=1):
+    """Fold Jacobian partial sums (the multi-GPU exchange records) into one affine point."""
+    cols = 18 if group == 1 else 36
+    records = _u64(records, cols)
+    out = np.zeros(12 if group == 1 else 24, np.uint64)
+    inf = C.c_int(0)
+    ctx.check(ctx.lib.vsp_fold_jacobian(ctx.h, group, _ptr(records), records.shape[0], _ptr(out), C.byref(inf)))
+    return out
+
+
+# ---- evaluation_domain (a6) -------------------------------------------------------------------
+class EvaluationDomain:
+    """math::evaluation_domain<Fr> for a power-of-two size (basic_radix2_domain).
+    Methods take and return host arrays [m,4] of canonical Fr; *_device variants work in place on
+    device memory."""
+
+    def __init__(self, ctx, m):
+        if m < 1 or m & (m - 1):
+            raise ValueError("basic_radix2_domain: m must be a power of two")   # upstream throws for other sizes
+        self.ctx, self.m, self.log_m = ctx, m, m.bit_length() - 1
+
+    def _run(self, a, inverse, coset):
+        a = _u64(a, 4).copy()
+        if a.shape[0] != self.m:
+            raise ValueError("evaluation_domain: expected vector of size m")     # upstream: std::invalid_argument
+        g = None if coset is None else _u64(coset)
+        self.ctx.check(self.ctx.lib.vsp_ntt_fr(self.ctx.h, _ptr(a), self.log_m, int(inverse), _ptr(g)))
+        return a
+
+    def fft(self, a): return self._run(a, False, None)
+    def inverse_fft(self, a): return self._run(a, True, None)
+    def coset_fft(self, a, g): return self._run(a, False, g)
+    def inverse_coset_fft(self, a, g): return self._run(a, True, g)
+    cosetFFT = coset_fft
+    icosetFFT = inverse_coset_fft
+    iFFT = inverse_fft
+    FFT = fft
+
+    def fft_device(self, d_a, inverse=False, coset=None):
+        g = None if coset is None else _u64(coset)
+        self.ctx.check(self.ctx.lib.vsp_ntt_fr_device(self.ctx.h, _ptr(d_a), self.log_m, int(inverse), _ptr(g)))
+
+
+def make_evaluation_domain(ctx, min_size):
+    """math::make_evaluation_domain<Fr>(k) restricted to the radix-2 family: the smallest power of two >= k."""
+    m = 1
+    while m < min_size:
+        m *= 2
+    return EvaluationDomain(ctx, m)
+
+
+def witness_map_h(ctx, Az, Bz, Cz):
+    """r1cs_to_qap::witness_map tail (d1=d2=d3=0): coefficients of H from the evaluation vectors."""
+    Az, Bz, Cz = (_u64(x, 4).copy() for x in (Az, Bz, Cz))
+    m = Az.shape[0]
+    log_m = m.bit_length() - 1
+    if (1 << log_m) != m or Bz.shape[0] != m or Cz.shape[0] != m:
+        raise ValueError("witness_map: vectors must share one power-of-two length")
+    H = np.zeros((m, 4), np.uint64)
+    ctx.check(ctx.lib.vsp_witness_map_h(ctx.h, _ptr(Az), _ptr(Bz), _ptr(Cz), log_m, _ptr(H)))
+    return H
+
+
+# ---- Groth16 prover (a8, a9) ---------------------------------------------------------------------
+class R1CS:
+    """Device-resident constraint system: three CSR matrices (row_ptr u32, col u32, coeff [nnz,4] u64)."""
+
+    def __init__(self, ctx, num_constraints, num_inputs, num_vars, A, B, Cm):
+        self.ctx = ctx
+        self.num_constraints, self.num_inputs, self.num_vars = num_constraints, num_inputs, num_vars
+        args = []
+        self._keep = []
+        for rp, ci, co in (A, B, Cm):
+            rp = np.ascontiguousarray(rp, dtype=np.uint32); ci = np.ascontiguousarray(ci, dtype=np.uint32); co = _u64(co, 4)
+            if rp.shape[0] != num_constraints + 1 or ci.shape[0] != rp[-1] or co.shape[0] != rp[-1]:
+                raise ValueError("R1CS: malformed CSR")
+            self._keep += [rp, ci, co]
+            args += [_ptr(rp), _ptr(ci), _ptr(co)]
+        self.h = ctx.lib.vsp_r1cs_upload(ctx.h, num_constraints, num_inputs, num_vars, *args)
+        if not self.h:
+            raise VspError("r1cs upload failed: " + ctx.last_error())
+        self._keep = None
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_r1cs_free(self.ctx.h, self.h)
+        self.h = None
+
+
+class ProvingKey:
+    """r1cs_gg_ppzksnark proving key with device-resident queries."""
+
+    def __init__(self, ctx, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, A_query, B_query_g1, B_query_g2, H_query, L_query):
+        self.ctx = ctx
+        self.queries = (A_query, B_query_g1, B_query_g2, H_query, L_query)
+        consts = [_u64(x) for x in (alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2)]
+        self.h = ctx.lib.vsp_pk_create(ctx.h, *[_ptr(c) for c in consts], *[q.h for q in self.queries])
+        if not self.h:
+            raise VspError("pk_create failed: " + ctx.last_error())
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_pk_free(self.ctx.h, self.h)
+        self.h = None
+
+
+def groth16_prove(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
+    """r1cs_gg_ppzksnark_prover::process with explicit r, s.  -> (A[12], B[24], C[12], proof_bytes[192])."""
+    witness = _u64(witness, 4)
+    if witness.shape[0] != cs.num_vars:
+        raise ValueError("prove: witness must have num_vars entries (primary || auxiliary)")
+    A = np.zeros(12, np.uint64); B = np.zeros(24, np.uint64); Cc = np.zeros(12, np.uint64)
+    proof = np.zeros(192, np.uint8)
+    p1 = None if saver_P1 is None else _u64(saver_P1)
+    re = None if saver_r_enc is None else _u64(saver_r_enc)
+    ctx.check(ctx.lib.vsp_groth16_prove(ctx.h, cs.h, pk.h, _ptr(witness), _ptr(_u64(r)), _ptr(_u64(s)), _ptr(p1), _ptr(re),
+                                        _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
+    return A, B, Cc, proof.tobytes()
+
+
+def fixed_base_mul(ctx, d_scalars, n, group=1):
+    """Generator-side batch_exp: device array out[i] = scalars[i] * generator (canonical affine).  Returns a device pointer."""
+    width = 96 if group == 1 else 192
+    d_out = ctx.dmalloc(max(n, 1) * width)
+    fn = ctx.lib.vsp_fixed_base_mul_g1 if group == 1 else ctx.lib.vsp_fixed_base_mul_g2
+    ctx.check(fn(ctx.h, _ptr(d_scalars), n, C.c_void_p(d_out)))
+    return d_out
+
+
+def g1_compress(affine):
+    out = np.zeros(48, np.uint8); _lib.load().vsp_g1_compress(_ptr(_u64(affine)), _ptr(out)); return out.tobytes()
+
+
+def g2_compress(affine):
+    out = np.zeros(96, np.uint8); _lib.load().vsp_g2_compress(_ptr(_u64(affine)), _ptr(out)); return out.tobytes()

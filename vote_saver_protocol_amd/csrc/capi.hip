@@ -1,0 +1,327 @@
+// extern "C" surface of libvsp_hip.so (declared in include/vsp.h): context, device memory, MSM / NTT /
+// witness_map entry points, Jacobian record folding and the ZCash point compression.
+#include "common.h"
+
+namespace vsp {
+
+int set_hip_error(vsp_ctx *ctx, hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    if (ctx) ctx->err = buf;
+    return VSP_ERR_HIP;
+}
+int set_error(vsp_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes && b.p) return VSP_OK;
+    if (b.p) { VSP_HIP(hipStreamSynchronize(ctx->stream)); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8;          // a little headroom so a slightly larger call does not realloc
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; char m[128]; snprintf(m, sizeof m, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return set_error(ctx, VSP_ERR_NOMEM, m); }
+    b.cap = want;
+    return VSP_OK;
+}
+
+static void free_buf(DevBuf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+static const uint64_t HALF_P[6] = {0xdcff7fffffffd555ULL, 0x0f55ffff58a9ffffULL, 0xb39869507b587b12ULL, 0xb23ba5c279c2895fULL, 0x258dd3db21a5d66bULL, 0x0d0088f51cbff34dULL};
+static bool fp_lex_larger(const uint64_t *y) {      // y > (p-1)/2
+    for (int i = 5; i >= 0; i--) { if (y[i] > HALF_P[i]) return true; if (y[i] < HALF_P[i]) return false; }
+    return false;
+}
+static bool limbs_zero(const uint64_t *a, int n) { uint64_t o = 0; for (int i = 0; i < n; i++) o |= a[i]; return o == 0; }
+static void be48(uint8_t *out, const uint64_t *l) { for (int i = 0; i < 6; i++) for (int b = 0; b < 8; b++) out[47 - (i * 8 + b)] = (uint8_t)(l[i] >> (8 * b)); }
+
+template <class F, class HF>
+static int finish_affine(const XYZZ<HF> &acc, uint64_t *out_affine, int *out_is_inf);
+template <> int finish_affine<Fp, HFp>(const XYZZ<HFp> &acc, uint64_t *out_affine, int *out_is_inf) {
+    Affine<HFp> a = xyzz_to_affine(acc);
+    if (out_affine) host_store_g1(out_affine, a);
+    if (out_is_inf) *out_is_inf = is_inf(acc) ? 1 : 0;
+    return VSP_OK;
+}
+template <> int finish_affine<Fp2, HFp2>(const XYZZ<HFp2> &acc, uint64_t *out_affine, int *out_is_inf) {
+    Affine<HFp2> a = xyzz_to_affine(acc);
+    if (out_affine) host_store_g2(out_affine, a);
+    if (out_is_inf) *out_is_inf = is_inf(acc) ? 1 : 0;
+    return VSP_OK;
+}
+
+}  // namespace vsp
+
+using namespace vsp;
+
+extern "C" {
+
+vsp_ctx *vsp_create(int device_ordinal) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_ordinal < 0 || device_ordinal >= count) return nullptr;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return nullptr;
+    vsp_ctx *ctx = new vsp_ctx();
+    ctx->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->stream = ctx->own_stream;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
+    return ctx;
+}
+
+void vsp_destroy(vsp_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch,
+                      &ctx->msm_cnt, &ctx->msm_off, &ctx->msm_cursor, &ctx->msm_nsub, &ctx->msm_suboff, &ctx->msm_blocksum, &ctx->msm_sorted,
+                      &ctx->msm_heavy, &ctx->msm_counters, &ctx->msm_buckets, &ctx->msm_partials, &ctx->msm_dims, &ctx->msm_winres,
+                      &ctx->msm_scalars, &ctx->msm_tmp_bases, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
+                      &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
+    for (DevBuf *b : bufs) free_buf(*b);
+    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *vsp_last_error(vsp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vsp_set_stream(vsp_ctx *ctx, void *hip_stream) {
+    if (!ctx) return VSP_ERR_ARG;
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VSP_OK;
+}
+int vsp_synchronize(vsp_ctx *ctx) {
+    if (!ctx) return VSP_ERR_ARG;
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+double vsp_get_stat(vsp_ctx *ctx, const char *name) {
+    if (!ctx || !name) return 0.0;
+    auto it = ctx->stats.find(name);
+    return it == ctx->stats.end() ? 0.0 : it->second;
+}
+void vsp_stats_reset(vsp_ctx *ctx) { if (ctx) ctx->stats.clear(); }
+int vsp_set_option(vsp_ctx *ctx, const char *name, long value) {
+    if (!ctx || !name) return VSP_ERR_ARG;
+    ctx->opts[name] = value;
+    return VSP_OK;
+}
+
+void *vsp_dmalloc(vsp_ctx *ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    hipSetDevice(ctx->device);
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { set_error(ctx, VSP_ERR_NOMEM, "vsp_dmalloc: hipMalloc failed"); return nullptr; }
+    return p;
+}
+void vsp_dfree(vsp_ctx *ctx, void *dptr) { if (ctx && dptr) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); hipFree(dptr); } }
+int vsp_h2d(vsp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return VSP_ERR_ARG;
+    VSP_HIP(hipSetDevice(ctx->device));
+    VSP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+int vsp_d2h(vsp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return VSP_ERR_ARG;
+    VSP_HIP(hipSetDevice(ctx->device));
+    VSP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+
+// ---- bases ------------------------------------------------------------------------------------
+static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n) {
+    if (!ctx) return nullptr;
+    if (!src && n) { set_error(ctx, VSP_ERR_ARG, "bases: null pointer"); return nullptr; }
+    hipSetDevice(ctx->device);
+    size_t esz = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
+    vsp_bases *b = new vsp_bases();
+    b->group = group; b->n = n;
+    if (hipMalloc(&b->d, n ? n * esz : 16) != hipSuccess) { set_error(ctx, VSP_ERR_NOMEM, "bases: hipMalloc failed"); delete b; return nullptr; }
+    if (n) {
+        int rc;
+        if (!src_on_device) {
+            if (hipMemcpyAsync(b->d, src, n * esz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { set_error(ctx, VSP_ERR_HIP, "bases: H2D failed"); hipFree(b->d); delete b; return nullptr; }
+            src = b->d;                      // convert in place
+        }
+        rc = group == 1 ? bases_to_mont_g1(ctx, src, (G1Affine *)b->d, n) : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n);
+        if (rc != VSP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(b->d); delete b; return nullptr; }
+    }
+    return b;
+}
+vsp_bases *vsp_bases_upload_g1(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_new(ctx, 1, bases, false, n); }
+vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_new(ctx, 2, bases, false, n); }
+vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_new(ctx, 1, d_bases, true, n); }
+vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_new(ctx, 2, d_bases, true, n); }
+size_t vsp_bases_count(const vsp_bases *b) { return b ? b->n : 0; }
+void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
+    if (!b) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    if (b->d) hipFree(b->d);
+    delete b;
+}
+
+// ---- MSM ----------------------------------------------------------------------------------------
+static int msm_resident_xyzz(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars,
+                             XYZZ<HFp> *o1, XYZZ<HFp2> *o2) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!bases || (!d_scalars && n)) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
+    if (first > bases->n || n > bases->n - first) return set_error(ctx, VSP_ERR_ARG, "msm: range outside the resident bases");
+    VSP_HIP(hipSetDevice(ctx->device));
+    if (bases->group == 1) return msm_g1_device(ctx, (const G1Affine *)bases->d + first, (const Fr *)d_scalars, n, o1);
+    return msm_g2_device(ctx, (const G2Affine *)bases->d + first, (const Fr *)d_scalars, n, o2);
+}
+
+int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, uint64_t *out_affine, int *out_is_inf) {
+    XYZZ<HFp> a1; XYZZ<HFp2> a2;
+    VSP_TRY(msm_resident_xyzz(ctx, bases, first, n, d_scalars, &a1, &a2));
+    return bases->group == 1 ? finish_affine<Fp, HFp>(a1, out_affine, out_is_inf) : finish_affine<Fp2, HFp2>(a2, out_affine, out_is_inf);
+}
+
+int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, uint64_t *out_jacobian) {
+    XYZZ<HFp> a1; XYZZ<HFp2> a2;
+    if (!out_jacobian) return set_error(ctx, VSP_ERR_ARG, "msm: null output");
+    VSP_TRY(msm_resident_xyzz(ctx, bases, first, n, d_scalars, &a1, &a2));
+    if (bases->group == 1) {
+        Jacobian<HFp> j = xyzz_to_jacobian(a1);
+        host_store_canon(out_jacobian, j.X); host_store_canon(out_jacobian + 6, j.Y); host_store_canon(out_jacobian + 12, j.Z);
+    } else {
+        Jacobian<HFp2> j = xyzz_to_jacobian(a2);
+        host_store_canon(out_jacobian, j.X.c0); host_store_canon(out_jacobian + 6, j.X.c1);
+        host_store_canon(out_jacobian + 12, j.Y.c0); host_store_canon(out_jacobian + 18, j.Y.c1);
+        host_store_canon(out_jacobian + 24, j.Z.c0); host_store_canon(out_jacobian + 30, j.Z.c1);
+    }
+    return VSP_OK;
+}
+
+int vsp_fold_jacobian(vsp_ctx *ctx, int group, const uint64_t *records, size_t count, uint64_t *out_affine, int *out_is_inf) {
+    if (!records && count) return set_error(ctx, VSP_ERR_ARG, "fold: null records");
+    if (group == 1) {
+        XYZZ<HFp> acc = XYZZ<HFp>::inf();
+        for (size_t i = 0; i < count; i++) {
+            const uint64_t *p = records + 18 * i;
+            Jacobian<HFp> j; j.X = host_load_canon<HFp>(p); j.Y = host_load_canon<HFp>(p + 6); j.Z = host_load_canon<HFp>(p + 12);
+            xyzz_add(acc, jacobian_to_xyzz(j));
+        }
+        return finish_affine<Fp, HFp>(acc, out_affine, out_is_inf);
+    } else if (group == 2) {
+        XYZZ<HFp2> acc = XYZZ<HFp2>::inf();
+        for (size_t i = 0; i < count; i++) {
+            const uint64_t *p = records + 36 * i;
+            Jacobian<HFp2> j;
+            j.X.c0 = host_load_canon<HFp>(p); j.X.c1 = host_load_canon<HFp>(p + 6);
+            j.Y.c0 = host_load_canon<HFp>(p + 12); j.Y.c1 = host_load_canon<HFp>(p + 18);
+            j.Z.c0 = host_load_canon<HFp>(p + 24); j.Z.c1 = host_load_canon<HFp>(p + 30);
+            xyzz_add(acc, jacobian_to_xyzz(j));
+        }
+        return finish_affine<Fp2, HFp2>(acc, out_affine, out_is_inf);
+    }
+    return set_error(ctx, VSP_ERR_ARG, "fold: group must be 1 or 2");
+}
+
+static int msm_host(vsp_ctx *ctx, int group, const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t *out_affine, int *out_is_inf) {
+    if (!ctx) return VSP_ERR_ARG;
+    if ((!bases || !scalars) && n) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
+    VSP_HIP(hipSetDevice(ctx->device));
+    vsp_bases *b = group == 1 ? vsp_bases_upload_g1(ctx, bases, n) : vsp_bases_upload_g2(ctx, bases, n);
+    if (!b) return VSP_ERR_NOMEM;
+    int rc = ensure(ctx, ctx->msm_scalars, n * 32);
+    if (rc == VSP_OK && n) {
+        if (hipMemcpyAsync(ctx->msm_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "msm: H2D of scalars failed");
+    }
+    if (rc == VSP_OK) rc = vsp_msm_resident(ctx, b, 0, n, ctx->msm_scalars.p, out_affine, out_is_inf);
+    vsp_bases_free(ctx, b);
+    return rc;
+}
+int vsp_msm_g1(vsp_ctx *ctx, const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_affine[12], int *out_is_inf) {
+    return msm_host(ctx, 1, bases, scalars, n, out_affine, out_is_inf);
+}
+int vsp_msm_g2(vsp_ctx *ctx, const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t out_affine[24], int *out_is_inf) {
+    return msm_host(ctx, 2, bases, scalars, n, out_affine, out_is_inf);
+}
+
+// ---- NTT / witness_map ------------------------------------------------------------------------
+int vsp_ntt_fr_device(vsp_ctx *ctx, void *d_a, unsigned log_m, int inverse, const uint64_t coset_g[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d_a) return set_error(ctx, VSP_ERR_ARG, "ntt: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    return ntt_device(ctx, (Fr *)d_a, log_m, inverse, coset_g, nullptr);
+}
+int vsp_ntt_fr(vsp_ctx *ctx, uint64_t *a, unsigned log_m, int inverse, const uint64_t coset_g[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!a) return set_error(ctx, VSP_ERR_ARG, "ntt: null pointer");
+    if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: log_m > 28");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t bytes = ((size_t)1 << log_m) * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_h.p, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_TRY(ntt_device(ctx, (Fr *)ctx->pr_h.p, log_m, inverse, coset_g, nullptr));
+    VSP_HIP(hipMemcpyAsync(a, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+int vsp_witness_map_h_device(vsp_ctx *ctx, void *d_Az, void *d_Bz, void *d_Cz, unsigned log_m, void *d_H) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d_Az || !d_Bz || !d_Cz || !d_H) return set_error(ctx, VSP_ERR_ARG, "witness_map: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    return witness_map_device(ctx, (Fr *)d_Az, (Fr *)d_Bz, (Fr *)d_Cz, log_m, (Fr *)d_H);
+}
+int vsp_witness_map_h(vsp_ctx *ctx, uint64_t *Az, uint64_t *Bz, uint64_t *Cz, unsigned log_m, uint64_t *H) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!Az || !Bz || !Cz || !H) return set_error(ctx, VSP_ERR_ARG, "witness_map: null pointer");
+    if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "witness_map: log_m > 28");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t bytes = ((size_t)1 << log_m) * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_a, bytes)); VSP_TRY(ensure(ctx, ctx->pr_b, bytes));
+    VSP_TRY(ensure(ctx, ctx->pr_c, bytes)); VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_a.p, Az, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_b.p, Bz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_c.p, Cz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_TRY(witness_map_device(ctx, (Fr *)ctx->pr_a.p, (Fr *)ctx->pr_b.p, (Fr *)ctx->pr_c.p, log_m, (Fr *)ctx->pr_h.p));
+    VSP_HIP(hipMemcpyAsync(H, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+
+// ---- generator-side batch exponentiation ---------------------------------------------------------
+int vsp_fixed_base_mul_g1(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    if ((!d_scalars || !d_out) && n) return set_error(ctx, VSP_ERR_ARG, "fixed_base_mul: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    VSP_TRY(fixed_base_mul_g1(ctx, (const Fr *)d_scalars, n, d_out));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    if ((!d_scalars || !d_out) && n) return set_error(ctx, VSP_ERR_ARG, "fixed_base_mul: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    VSP_TRY(fixed_base_mul_g2(ctx, (const Fr *)d_scalars, n, d_out));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+
+// ---- ZCash compressed encoding (the wire format of reference bin/cli/src/data.bin[0:192]) ----------
+int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]) {
+    if (!affine || !out) return VSP_ERR_ARG;
+    if (limbs_zero(affine, 12)) { memset(out, 0, 48); out[0] = 0xC0; return VSP_OK; }
+    be48(out, affine);
+    out[0] |= 0x80;
+    if (fp_lex_larger(affine + 6)) out[0] |= 0x20;
+    return VSP_OK;
+}
+int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]) {
+    if (!affine || !out) return VSP_ERR_ARG;
+    if (limbs_zero(affine, 24)) { memset(out, 0, 96); out[0] = 0xC0; return VSP_OK; }
+    be48(out, affine + 6);          // x.c1 first
+    be48(out + 48, affine);         // then x.c0
+    out[0] |= 0x80;
+    const uint64_t *y0 = affine + 12, *y1 = affine + 18;
+    bool larger = limbs_zero(y1, 6) ? fp_lex_larger(y0) : fp_lex_larger(y1);
+    if (larger) out[0] |= 0x20;
+    return VSP_OK;
+}
+
+}  // extern "C"

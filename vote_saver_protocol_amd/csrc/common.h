@@ -1,0 +1,120 @@
+// Internal definitions shared by the translation units of libvsp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vsp.h"
+#include "curve.h"
+
+namespace vsp {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// stage [s0, s1) split of one NTT (see ntt.hip)
+struct NttTables {
+    DevBuf fwd, inv;        // omega^j and omega^-j, j < 2^(log-1), Montgomery form
+    unsigned log = 0;       // domain log the tables were generated for (serves every smaller domain)
+    // two-level coset power tables for the cached coset generator
+    DevBuf pw_lo_f, pw_hi_f, pw_lo_i, pw_hi_i;
+    unsigned pw_log = 0;    // log_m the hi tables were sized for
+    uint64_t pw_g[4] = {0, 0, 0, 0};
+    bool pw_valid = false;
+};
+
+}  // namespace vsp
+
+struct vsp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // created by vsp_create
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::map<std::string, double> stats;
+    std::map<std::string, long> opts;
+    vsp::NttTables ntt;
+    vsp::DevBuf ntt_scratch;
+    // MSM workspaces (grow only)
+    vsp::DevBuf msm_cnt, msm_off, msm_cursor, msm_nsub, msm_suboff, msm_blocksum, msm_sorted, msm_heavy, msm_counters;
+    vsp::DevBuf msm_buckets, msm_partials, msm_dims, msm_winres, msm_scalars, msm_tmp_bases;
+    // fixed-base tables (generator multiples), built lazily
+    vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
+    // prover workspaces
+    vsp::DevBuf pr_z, pr_a, pr_b, pr_c, pr_h;
+};
+
+struct vsp_bases {
+    int group = 1;          // 1 = G1, 2 = G2
+    size_t n = 0;
+    void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form
+};
+
+struct vsp_r1cs {
+    size_t num_constraints = 0, num_inputs = 0, num_vars = 0;
+    unsigned log_m = 0;
+    uint32_t *rp[3] = {nullptr, nullptr, nullptr};
+    uint32_t *ci[3] = {nullptr, nullptr, nullptr};
+    void *co[3] = {nullptr, nullptr, nullptr};      // Fr Montgomery
+};
+
+struct vsp_pk {
+    vsp::Affine<vsp::HFp> alpha_g1, beta_g1, delta_g1;     // host, Montgomery
+    vsp::Affine<vsp::HFp2> beta_g2, delta_g2;
+    const vsp_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *H = nullptr, *L = nullptr;
+};
+
+namespace vsp {
+
+int set_hip_error(vsp_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
+int set_error(vsp_ctx *ctx, int code, const char *msg);
+int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
+
+#define VSP_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return vsp::set_hip_error(ctx, e_, #call, __FILE__, __LINE__); \
+    } while (0)
+#define VSP_TRY(call)                \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != VSP_OK) return rc_; \
+    } while (0)
+#define VSP_LAUNCH_CHECK() VSP_HIP(hipGetLastError())
+
+// ---- internal entry points (each implemented in its own .hip) ----
+int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr *dH);
+
+// MSM on device-resident Montgomery bases; result as host XYZZ (Montgomery, 64-bit limbs)
+int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);
+int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp2> *out);
+int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n);
+int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n);
+int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
+int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
+
+// canonical <-> host Montgomery helpers
+template <class F> inline F host_load_canon(const uint64_t *p) { F t; memcpy(&t, p, sizeof(F)); return to_mont(t); }
+template <class F> inline void host_store_canon(uint64_t *p, const F &m) { F t = from_mont(m); memcpy(p, &t, sizeof(F)); }
+inline Affine<HFp> host_load_g1(const uint64_t *p) { Affine<HFp> a; a.x = host_load_canon<HFp>(p); a.y = host_load_canon<HFp>(p + 6); return a; }
+inline Affine<HFp2> host_load_g2(const uint64_t *p) {
+    Affine<HFp2> a;
+    a.x.c0 = host_load_canon<HFp>(p); a.x.c1 = host_load_canon<HFp>(p + 6);
+    a.y.c0 = host_load_canon<HFp>(p + 12); a.y.c1 = host_load_canon<HFp>(p + 18);
+    return a;
+}
+inline void host_store_g1(uint64_t *p, const Affine<HFp> &a) { host_store_canon(p, a.x); host_store_canon(p + 6, a.y); }
+inline void host_store_g2(uint64_t *p, const Affine<HFp2> &a) {
+    host_store_canon(p, a.x.c0); host_store_canon(p + 6, a.x.c1); host_store_canon(p + 12, a.y.c0); host_store_canon(p + 18, a.y.c1);
+}
+
+static inline unsigned ceil_log2(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+}  // namespace vsp

@@ -1,0 +1,164 @@
+// Short-Weierstrass a=0 group law (BLS12-381 G1 over Fp, G2 over Fp2) in XYZZ coordinates:
+//   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2, infinity <=> ZZ = 0.
+// Mixed addition costs 8M+2S, full addition 12M+2S, doubling 6M+3S (EFD madd-2008-s, add-2008-s,
+// dbl-2008-s-1) -- cheaper than the Jacobian form the reference's CPU code uses
+// (crypto3-algebra curves/detail/forms/short_weierstrass/jacobian_with_a4_0, absent submodule;
+// coordinate names at bin/cli/include/nil/vote_saver/common.hpp:117-121).  Results leave this
+// library only as affine points (or as Jacobian X,Y,Z records for the multi-GPU exchange), which
+// are unique, so the internal coordinate system does not affect parity.
+//
+// Generic over the field type F (device: Fp / Fp2 with 32-bit limbs; host: HFp / HFp2).
+#pragma once
+#include "field.h"
+
+namespace vsp {
+
+// affine point; infinity is encoded as x = y = 0 (not on either curve since b != 0)
+template <class F> struct alignas(16) Affine {
+    F x, y;
+};
+template <class F> VSP_HD bool is_inf(const Affine<F> &p) { return is_zero(p.x) && is_zero(p.y); }
+
+template <class F> struct alignas(16) XYZZ {
+    F X, Y, ZZ, ZZZ;
+    VSP_HD static XYZZ inf() { XYZZ r; r.X = F::zero(); r.Y = F::zero(); r.ZZ = F::zero(); r.ZZZ = F::zero(); return r; }
+};
+template <class F> VSP_HD bool is_inf(const XYZZ<F> &p) { return is_zero(p.ZZ); }
+
+template <class F> VSP_HD XYZZ<F> xyzz_from_affine(const Affine<F> &p) {
+    XYZZ<F> r;
+    if (is_inf(p)) return XYZZ<F>::inf();
+    r.X = p.x; r.Y = p.y; r.ZZ = F::one(); r.ZZZ = F::one();
+    return r;
+}
+
+template <class F> VSP_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
+    if (is_inf(p)) return p;
+    F U = dbl(p.Y);
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(p.X, V);
+    F XX = sqr(p.X);
+    F M = add(dbl(XX), XX);
+    XYZZ<F> r;
+    r.X = sub(sqr(M), dbl(S));
+    r.Y = sub(mul(M, sub(S, r.X)), mul(W, p.Y));
+    r.ZZ = mul(V, p.ZZ);
+    r.ZZZ = mul(W, p.ZZZ);
+    return r;       // Y = 0 cannot occur: the groups have odd order
+}
+
+// doubling of an affine point (ZZ = ZZZ = 1)
+template <class F> VSP_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
+    F U = dbl(p.y);
+    F V = sqr(U);
+    F W = mul(U, V);
+    F S = mul(p.x, V);
+    F XX = sqr(p.x);
+    F M = add(dbl(XX), XX);
+    XYZZ<F> r;
+    r.X = sub(sqr(M), dbl(S));
+    r.Y = sub(mul(M, sub(S, r.X)), mul(W, p.y));
+    r.ZZ = V;
+    r.ZZZ = W;
+    return r;
+}
+
+// acc += q (q affine, optionally negated).  All exceptional cases handled.
+template <class F> VSP_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bool negate = false) {
+    if (is_inf(q_in)) return;
+    Affine<F> q = q_in;
+    if (negate) q.y = neg(q.y);
+    if (is_inf(acc)) { acc.X = q.x; acc.Y = q.y; acc.ZZ = F::one(); acc.ZZZ = F::one(); return; }
+    F U2 = mul(q.x, acc.ZZ);
+    F S2 = mul(q.y, acc.ZZZ);
+    F P = sub(U2, acc.X);
+    F R = sub(S2, acc.Y);
+    if (is_zero(P)) {
+        if (is_zero(R)) acc = xyzz_dbl_affine(q);
+        else acc = XYZZ<F>::inf();
+        return;
+    }
+    F PP = sqr(P);
+    F PPP = mul(P, PP);
+    F Q = mul(acc.X, PP);
+    F X3 = sub(sub(sqr(R), PPP), dbl(Q));
+    acc.Y = sub(mul(R, sub(Q, X3)), mul(acc.Y, PPP));
+    acc.X = X3;
+    acc.ZZ = mul(acc.ZZ, PP);
+    acc.ZZZ = mul(acc.ZZZ, PPP);
+}
+
+// acc += q (both XYZZ)
+template <class F> VSP_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
+    if (is_inf(q)) return;
+    if (is_inf(acc)) { acc = q; return; }
+    F U1 = mul(acc.X, q.ZZ);
+    F U2 = mul(q.X, acc.ZZ);
+    F S1 = mul(acc.Y, q.ZZZ);
+    F S2 = mul(q.Y, acc.ZZZ);
+    F P = sub(U2, U1);
+    F R = sub(S2, S1);
+    if (is_zero(P)) {
+        if (is_zero(R)) acc = xyzz_dbl(acc);
+        else acc = XYZZ<F>::inf();
+        return;
+    }
+    F PP = sqr(P);
+    F PPP = mul(P, PP);
+    F Q = mul(U1, PP);
+    F X3 = sub(sub(sqr(R), PPP), dbl(Q));
+    acc.Y = sub(mul(R, sub(Q, X3)), mul(S1, PPP));
+    acc.X = X3;
+    acc.ZZ = mul(mul(acc.ZZ, q.ZZ), PP);
+    acc.ZZZ = mul(mul(acc.ZZZ, q.ZZZ), PPP);
+}
+
+template <class F> VSP_HD XYZZ<F> xyzz_neg(const XYZZ<F> &p) { XYZZ<F> r = p; r.Y = neg(p.Y); return r; }
+
+// ---- host-side helpers (used with HFp / HFp2; cheap, a handful of calls per MSM / proof) ----
+template <class F> VSP_HD Affine<F> xyzz_to_affine(const XYZZ<F> &p) {
+    Affine<F> r;
+    if (is_inf(p)) { r.x = F::zero(); r.y = F::zero(); return r; }
+    F zi = inv(p.ZZZ);                 // 1/Z^3
+    F z = mul(zi, p.ZZ);               // Z^2/Z^3 = 1/Z
+    F zi2 = sqr(z);                    // 1/Z^2
+    r.x = mul(p.X, zi2);
+    r.y = mul(p.Y, zi);
+    return r;
+}
+
+// XYZZ -> Jacobian (X', Y', Z') with x = X'/Z'^2, y = Y'/Z'^3: take Z' = ZZZ, X' = X*ZZ^2, Y' = Y*ZZZ^2.
+// This is the 144-byte (G1) / 288-byte (G2) partial-sum record exchanged between GPUs.
+template <class F> struct alignas(16) Jacobian { F X, Y, Z; };
+template <class F> VSP_HD Jacobian<F> xyzz_to_jacobian(const XYZZ<F> &p) {
+    Jacobian<F> r;
+    if (is_inf(p)) { r.X = F::one(); r.Y = F::one(); r.Z = F::zero(); return r; }
+    r.X = mul(p.X, sqr(p.ZZ));
+    r.Y = mul(p.Y, sqr(p.ZZZ));
+    r.Z = p.ZZZ;
+    return r;
+}
+template <class F> VSP_HD XYZZ<F> jacobian_to_xyzz(const Jacobian<F> &p) {
+    XYZZ<F> r;
+    if (is_zero(p.Z)) return XYZZ<F>::inf();
+    r.X = p.X; r.Y = p.Y; r.ZZ = sqr(p.Z); r.ZZZ = mul(r.ZZ, p.Z);
+    return r;
+}
+
+// k * p for a canonical scalar given as nbits little-endian bits in 64-bit words (host side)
+template <class F> VSP_HD XYZZ<F> xyzz_mul_scalar(const XYZZ<F> &p, const uint64_t *k, int nbits) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int i = nbits - 1; i >= 0; i--) {
+        acc = xyzz_dbl(acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+using G1Affine = Affine<Fp>;
+using G2Affine = Affine<Fp2>;
+using G1XYZZ = XYZZ<Fp>;
+using G2XYZZ = XYZZ<Fp2>;
+
+}  // namespace vsp

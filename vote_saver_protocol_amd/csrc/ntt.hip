@@ -1,0 +1,287 @@
+// Radix-2 NTT over BLS12-381 Fr for gfx950, plus the pointwise kernels of r1cs_to_qap::witness_map.
+//
+// Replaces math::evaluation_domain<Fr> / basic_radix2_domain (fft, inverse_fft, coset variants,
+// divide_by_z_on_coset) of crypto3-math -- absent submodule, /root/reference/.gitmodules:47-48;
+// reached from bin/cli/include/nil/vote_saver/common.hpp:1132-1135 via the prover's witness_map.
+// The serial reference algorithm is bit-reverse + log2(m) butterfly stages over one array
+// (libfqfft _basic_serial_radix2_FFT); the output is the DFT, unique given omega.
+//
+// MI355X design:
+//  * The log2(m) stages are grouped into passes of <= 8 stages.  One workgroup (256 threads) owns a
+//    tile of 2048 elements (64 KiB of LDS, two workgroups per CU), runs all of the pass's stages out
+//    of LDS and touches HBM exactly once for read and once for write: traffic per pass = 64 B/element,
+//    2-4 passes per transform (m = 2^22: 3 passes, 8+7+7 stages).
+//  * A tile is [2^K butterfly rows] x [C = 2048/2^K contiguous columns]; every global access is a run
+//    of C*32 bytes >= 256 B.  The first pass reads through the bit-reversal permutation (runs of C
+//    inputs) and writes natural order, so no separate permutation pass exists.
+//  * Values stay CANONICAL in HBM and LDS: a Montgomery product of a canonical value with a
+//    Montgomery-form twiddle is already the canonical product, so no domain conversion is ever done.
+//  * LDS holds each 32-byte element as two 16-byte halves in separate planes: a wave's ds_read_b128 /
+//    ds_write_b128 then covers 64 x 16 contiguous bytes (conflict-free), instead of a 32-byte stride.
+//  * Twiddles come from one table omega^j, j < m/2 (64 MiB at m = 2^22, Infinity-Cache resident);
+//    the table of the largest domain seen serves every smaller one by striding.
+//  * Coset shift (a[j] *= g^j), inverse scaling (m^-1) and inverse coset shift are fused into the
+//    first pass's load / the last pass's store.
+//  * The path is integer-ALU bound (one 8-limb Montgomery product per butterfly), not HBM bound.
+#include "common.h"
+
+namespace vsp {
+
+static constexpr unsigned NTT_TILE_LOG = 11;      // 2048 elements per workgroup
+static constexpr unsigned NTT_THREADS = 256;
+static constexpr unsigned NTT_MAX_STAGES = 8;     // per pass (keeps C >= 8 columns = 256 B runs)
+static constexpr unsigned PW_LOG = 11;            // two-level power tables: g^i = lo[i & 2047] * hi[i >> 11]
+
+struct NttPassArgs {
+    unsigned log_n, s0, s1, clog, tlog;
+    int first, last;
+    int premul;     // multiply input i by g^i (forward coset), first pass only
+    int postmul;    // last pass only: 0 none, 1 constant `scale`, 2 scale * ginv^pos
+    const Fr *tw;
+    const Fr *pw_lo, *pw_hi;
+    Fr scale;       // Montgomery form
+};
+
+__device__ __forceinline__ unsigned brev(unsigned v, unsigned bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+__device__ __forceinline__ Fr lds_load(const uint4 *pl0, const uint4 *pl1, unsigned e) {
+    Fr v; uint4 a = pl0[e], b = pl1[e];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
+}
+__device__ __forceinline__ void lds_store(uint4 *pl0, uint4 *pl1, unsigned e, const Fr &v) {
+    pl0[e] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    pl1[e] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const Fr *__restrict__ in, Fr *__restrict__ out, NttPassArgs p) {
+    __shared__ uint4 lds[2u << NTT_TILE_LOG];
+    const unsigned K = p.s1 - p.s0;
+    const unsigned C = 1u << p.clog;
+    const unsigned tile = 1u << (K + p.clog);
+    uint4 *pl0 = lds, *pl1 = lds + tile;
+    const unsigned tid = threadIdx.x;
+    const unsigned wg = blockIdx.x;
+    // position pieces for passes after the first: pos = hi<<s1 | mid<<s0 | lo_hi<<clog | c
+    const unsigned lo_bits = p.s0 - p.clog;                   // only meaningful when !first
+    const unsigned lo_hi = p.first ? 0u : (wg & ((1u << lo_bits) - 1u));
+    const unsigned hi = p.first ? 0u : (wg >> lo_bits);
+    const size_t base_pos = p.first ? 0 : (((size_t)hi << p.s1) | ((size_t)lo_hi << p.clog));
+
+    // ---- load tile (LDS index e = mid*C + c; consecutive threads -> consecutive c -> contiguous HBM)
+    for (unsigned e = tid; e < tile; e += NTT_THREADS) {
+        unsigned mid = e >> p.clog, c = e & (C - 1);
+        size_t src;
+        if (p.first) src = ((size_t)brev(mid, p.s1) << (p.log_n - p.s1)) + (size_t)wg * C + c;
+        else src = base_pos | ((size_t)mid << p.s0) | c;
+        Fr v = in[src];
+        if (p.premul) {
+            Fr g = mul(p.pw_lo[src & ((1u << PW_LOG) - 1u)], p.pw_hi[src >> PW_LOG]);
+            v = mul(v, g);
+        }
+        lds_store(pl0, pl1, e, v);
+    }
+    __syncthreads();
+
+    // ---- K butterfly stages out of LDS
+    const unsigned lo_part = p.first ? 0u : ((lo_hi << p.clog));
+    for (unsigned t = 0; t < K; t++) {
+        const unsigned s = p.s0 + t;          // global stage: half-size 2^s, twiddle omega_{2^(s+1)}^j
+        const unsigned h = 1u << t;
+        for (unsigned bf = tid; bf < (tile >> 1); bf += NTT_THREADS) {
+            unsigned c = bf & (C - 1), q = bf >> p.clog;
+            unsigned mid_lo = q & (h - 1);
+            unsigned mid0 = ((q >> t) << (t + 1)) | mid_lo;
+            unsigned e0 = (mid0 << p.clog) | c, e1 = e0 + (h << p.clog);
+            Fr u = lds_load(pl0, pl1, e0), v = lds_load(pl0, pl1, e1);
+            if (s > 0) {
+                size_t j = ((size_t)mid_lo << p.s0) | (p.first ? 0u : (lo_part | c));
+                v = mul(v, p.tw[j << (p.tlog - 1 - s)]);
+            }
+            lds_store(pl0, pl1, e0, add(u, v));
+            lds_store(pl0, pl1, e1, sub(u, v));
+        }
+        __syncthreads();
+    }
+
+    // ---- store tile
+    for (unsigned i = tid; i < tile; i += NTT_THREADS) {
+        unsigned mid, c; size_t pos;
+        if (p.first) {              // natural-order output: runs of 2^K contiguous elements per column
+            mid = i & ((1u << K) - 1u); c = i >> K;
+            pos = ((size_t)brev(wg * C + c, p.log_n - p.s1) << p.s1) | mid;
+        } else {
+            mid = i >> p.clog; c = i & (C - 1);
+            pos = base_pos | ((size_t)mid << p.s0) | c;
+        }
+        Fr v = lds_load(pl0, pl1, (mid << p.clog) | c);
+        if (p.last && p.postmul) {
+            Fr m = p.scale;
+            if (p.postmul == 2) m = mul(m, mul(p.pw_lo[pos & ((1u << PW_LOG) - 1u)], p.pw_hi[pos >> PW_LOG]));
+            v = mul(v, m);
+        }
+        out[pos] = v;
+    }
+}
+
+// T[j] = A[j & 2047] * B[j >> 11]  (all Montgomery)
+__global__ void k_fill_twiddles(Fr *T, const Fr *A, const Fr *B, size_t count) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) T[j] = mul(A[j & ((1u << PW_LOG) - 1u)], B[j >> PW_LOG]);
+}
+
+// ---- pointwise kernels of witness_map --------------------------------------------------------
+// h[i] = montmul(a[i], b[i]) - montmul(c[i], 1) = (a*b - c) / R  (canonical a, b, c).  The missing
+// factor R, the divide_by_z_on_coset constant 1/Z(g) and m^-1 are folded into the scale constant of
+// the inverse coset transform that follows, so this stays at two products per element.
+__global__ void k_ab_minus_c(Fr *h, const Fr *a, const Fr *b, const Fr *c, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = sub(mul(a[i], b[i]), mul(c[i], Fr::raw_one()));
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static const uint64_t FR_ROOT_2_32[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL};
+
+static HFr host_omega(unsigned log_m) {
+    HFr w = host_load_canon<HFr>(FR_ROOT_2_32);
+    for (unsigned i = log_m; i < 32; i++) w = sqr(w);
+    return w;
+}
+static HFr host_from_u64(uint64_t v) { uint64_t c[4] = {v, 0, 0, 0}; return host_load_canon<HFr>(c); }
+
+static Fr to_dev(const HFr &h) { Fr d; memcpy(&d, &h, sizeof(Fr)); return d; }
+
+// lo[k] = base^k (k < 2^PW_LOG), hi[k] = base^(k << PW_LOG) (k < hi_count), Montgomery form
+static int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi) {
+    const size_t L = (size_t)1 << PW_LOG;
+    std::vector<HFr> a(L), b(hi_count);
+    HFr acc = HFr::one();
+    for (size_t k = 0; k < L; k++) { a[k] = acc; acc = mul(acc, base); }
+    HFr step = acc;                      // base^(2^PW_LOG)
+    acc = HFr::one();
+    for (size_t k = 0; k < hi_count; k++) { b[k] = acc; acc = mul(acc, step); }
+    VSP_TRY(ensure(ctx, lo, L * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, hi, hi_count * sizeof(Fr)));
+    VSP_HIP(hipMemcpyAsync(lo.p, a.data(), L * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipMemcpyAsync(hi.p, b.data(), hi_count * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));     // a, b go out of scope
+    return VSP_OK;
+}
+
+static int ensure_twiddles(vsp_ctx *ctx, unsigned log_m) {
+    NttTables &t = ctx->ntt;
+    if (t.log >= log_m && t.fwd.p) return VSP_OK;
+    unsigned lg = log_m < 1 ? 1 : log_m;
+    size_t count = (size_t)1 << (lg - 1);
+    size_t hi_count = count > ((size_t)1 << PW_LOG) ? (count >> PW_LOG) : 1;
+    DevBuf lo, hi;
+    for (int dir = 0; dir < 2; dir++) {
+        HFr w = host_omega(lg);
+        if (dir) w = inv(w);
+        VSP_TRY(upload_power_tables(ctx, w, hi_count, lo, hi));
+        DevBuf &dst = dir ? t.inv : t.fwd;
+        VSP_TRY(ensure(ctx, dst, count * sizeof(Fr)));
+        unsigned blocks = (unsigned)((count + 255) / 256);
+        hipLaunchKernelGGL(k_fill_twiddles, dim3(blocks), dim3(256), 0, ctx->stream, (Fr *)dst.p, (const Fr *)lo.p, (const Fr *)hi.p, count);
+        VSP_LAUNCH_CHECK();
+    }
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(lo.p); hipFree(hi.p);
+    t.log = lg;
+    return VSP_OK;
+}
+
+static int ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4) {
+    NttTables &t = ctx->ntt;
+    if (t.pw_valid && t.pw_log >= log_m && memcmp(t.pw_g, g4, 32) == 0) return VSP_OK;
+    size_t n = (size_t)1 << log_m;
+    size_t hi_count = n > ((size_t)1 << PW_LOG) ? (n >> PW_LOG) : 1;
+    HFr g = host_load_canon<HFr>(g4);
+    VSP_TRY(upload_power_tables(ctx, g, hi_count, t.pw_lo_f, t.pw_hi_f));
+    VSP_TRY(upload_power_tables(ctx, inv(g), hi_count, t.pw_lo_i, t.pw_hi_i));
+    memcpy(t.pw_g, g4, 32); t.pw_log = log_m; t.pw_valid = true;
+    return VSP_OK;
+}
+
+// d_a: n canonical Fr values in device memory, transformed in place.
+// extra_scale (optional, host Montgomery): an additional constant multiplied into every output.
+int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: log_m > 28");
+    if (coset_g) {
+        uint64_t z = coset_g[0] | coset_g[1] | coset_g[2] | coset_g[3];
+        if (!z) return set_error(ctx, VSP_ERR_ARG, "ntt: coset generator is zero");
+    }
+    VSP_TRY(ensure_twiddles(ctx, log_m));
+    if (coset_g) VSP_TRY(ensure_coset_tables(ctx, log_m, coset_g));
+    const size_t n = (size_t)1 << log_m;
+
+    // pass plan
+    unsigned npass = log_m <= NTT_TILE_LOG ? 1 : (log_m + NTT_MAX_STAGES - 1) / NTT_MAX_STAGES;
+    unsigned stages[8];
+    for (unsigned i = 0; i < npass; i++) stages[i] = log_m / npass + (i < log_m % npass ? 1 : 0);
+
+    Fr *scratch = nullptr;
+    if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * sizeof(Fr))); scratch = (Fr *)ctx->ntt_scratch.p; }
+
+    HFr scale = HFr::one();
+    bool have_scale = false;
+    if (inverse) { scale = inv(host_from_u64((uint64_t)n)); have_scale = true; }
+    if (extra_scale) { scale = mul(scale, *extra_scale); have_scale = true; }
+
+    unsigned s0 = 0;
+    for (unsigned i = 0; i < npass; i++) {
+        NttPassArgs p;
+        memset(&p, 0, sizeof p);
+        p.log_n = log_m; p.s0 = s0; p.s1 = s0 + stages[i];
+        p.tlog = ctx->ntt.log;
+        p.first = (i == 0); p.last = (i == npass - 1);
+        p.clog = npass == 1 ? 0 : NTT_TILE_LOG - stages[i];
+        p.tw = (const Fr *)(inverse ? ctx->ntt.inv.p : ctx->ntt.fwd.p);
+        p.premul = (p.first && coset_g && !inverse) ? 1 : 0;
+        p.postmul = 0;
+        if (p.last) {
+            if (inverse && coset_g) p.postmul = 2;
+            else if (have_scale) p.postmul = 1;
+        }
+        if (p.premul) { p.pw_lo = (const Fr *)ctx->ntt.pw_lo_f.p; p.pw_hi = (const Fr *)ctx->ntt.pw_hi_f.p; }
+        if (p.postmul == 2) { p.pw_lo = (const Fr *)ctx->ntt.pw_lo_i.p; p.pw_hi = (const Fr *)ctx->ntt.pw_hi_i.p; }
+        p.scale = to_dev(scale);
+        if (!p.first && p.s0 < p.clog) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: pass plan");
+        const Fr *src = (i == 0) ? d_a : scratch;
+        Fr *dst = (npass == 1 || i == npass - 1) ? d_a : scratch;
+        unsigned tile_log = stages[i] + p.clog;
+        unsigned blocks = (unsigned)(n >> tile_log);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(blocks), dim3(NTT_THREADS), 0, ctx->stream, src, dst, p);
+        VSP_LAUNCH_CHECK();
+        s0 = p.s1;
+    }
+    if (log_m == 0 && have_scale) {
+        // m = 1: the transform is the identity; only an explicit extra scale would matter (not used)
+    }
+    ctx->stats["ntt_passes"] = (double)npass;
+    return VSP_OK;
+}
+
+// r1cs_to_qap::witness_map, d1 = d2 = d3 = 0:  H = icosetFFT( (cosetFFT(iFFT(A)) * cosetFFT(iFFT(B)) - cosetFFT(iFFT(C))) / Z(g) )
+// dA, dB, dC: m canonical values each (overwritten); dH receives the m coefficients of H.
+int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr *dH) {
+    static const uint64_t G7[4] = {7, 0, 0, 0};
+    const size_t m = (size_t)1 << log_m;
+    Fr *v[3] = {dA, dB, dC};
+    for (int k = 0; k < 3; k++) {
+        VSP_TRY(ntt_device(ctx, v[k], log_m, 1, nullptr, nullptr));
+        VSP_TRY(ntt_device(ctx, v[k], log_m, 0, G7, nullptr));
+    }
+    unsigned blocks = (unsigned)((m + 255) / 256);
+    hipLaunchKernelGGL(k_ab_minus_c, dim3(blocks), dim3(256), 0, ctx->stream, dH, (const Fr *)dA, (const Fr *)dB, (const Fr *)dC, m);
+    VSP_LAUNCH_CHECK();
+    // fold: R (from the plain Montgomery products above) * 1/Z(g),  Z(g) = g^m - 1
+    HFr g = host_from_u64(7), zc = g;
+    for (unsigned i = 0; i < log_m; i++) zc = sqr(zc);
+    zc = inv(sub(zc, HFr::one()));
+    HFr extra = mul(zc, HFr::r2());      // value zc * R in Montgomery form  (Mont(R) = R^2 mod r)
+    VSP_TRY(ntt_device(ctx, dH, log_m, 1, G7, &extra));
+    return VSP_OK;
+}
+
+}  // namespace vsp

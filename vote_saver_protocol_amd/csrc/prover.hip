@@ -1,0 +1,256 @@
+// Groth16 prover orchestration (r1cs_gg_ppzksnark_prover::process), the sparse R1CS mat-vec that feeds
+// r1cs_to_qap::witness_map, and the generator-side fixed-base batch exponentiation.
+//
+// Replaces, for the hot path, crypto3-zk r1cs_gg_ppzksnark/prover.hpp + reductions/r1cs_to_qap.hpp
+// (absent submodule, /root/reference/.gitmodules:11-12; README.md:272-273 points at prover.hpp#L73),
+// reached from bin/cli/include/nil/vote_saver/common.hpp:1132-1135; the generator's batch_exp is
+// reached from common.hpp:916-917.
+//
+//   A = alpha + sum z_i A_i + r delta          (G1)
+//   B = beta  + sum z_i B_i + s delta          (G2, and the same in G1 for C)
+//   C = sum h_i H_i + sum_{aux} z_i L_i + s A + r B_g1 - r s delta  (+ r_enc P1 in SAVER mode)
+#include "common.h"
+
+namespace vsp {
+
+// ---- sparse mat-vec: out[row] = sum_e coef[e] * z[col[e]],  z canonical, coef Montgomery -> canonical out
+__global__ void k_csr_matvec(const uint32_t *rp, const uint32_t *ci, const Fr *co, const Fr *z, size_t rows, Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    Fr acc = Fr::zero();
+    for (uint32_t e = rp[i]; e < rp[i + 1]; e++) acc = add(acc, mul(z[ci[e]], co[e]));
+    out[i] = acc;
+}
+__global__ void k_fr_to_mont(Fr *a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = to_mont(a[i]);
+}
+
+// ---- fixed-base windowed multiplication: 32 windows of 8 bits, table[w][d-1] = d * 256^w * G (affine, Montgomery)
+static constexpr int FB_WINDOWS = 32, FB_ENTRIES = 255;
+
+template <class F>
+__global__ void k_fixed_base(const Affine<F> *table, const Fr *scalars, size_t n, XYZZ<F> *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *kb = (const uint8_t *)scalars[i].l;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < FB_WINDOWS; w++) {
+        unsigned d = kb[w];
+        if (d) xyzz_madd(acc, table[w * FB_ENTRIES + d - 1]);
+    }
+    out[i] = acc;
+}
+
+// batch normalisation XYZZ -> canonical affine; each thread owns a chunk and does one inversion for it
+// (Montgomery's trick, prefix products kept in global scratch `pre`)
+static constexpr unsigned BA_CHUNK = 32;
+template <class F>
+__global__ void k_batch_affine(const XYZZ<F> *in, size_t n, F *pre, Affine<F> *out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t b = t * BA_CHUNK, e = b + BA_CHUNK < n ? b + BA_CHUNK : n;
+    if (b >= n) return;
+    F acc = F::one();
+    for (size_t i = b; i < e; i++) {
+        pre[i] = acc;
+        F z = in[i].ZZZ;
+        if (!is_zero(z)) acc = mul(acc, z);
+    }
+    F ai = inv(acc);
+    for (size_t i = e; i-- > b;) {
+        XYZZ<F> p = in[i];
+        Affine<F> r;
+        if (is_zero(p.ZZ)) { r.x = F::zero(); r.y = F::zero(); }
+        else {
+            F zi3 = mul(ai, pre[i]);          // 1 / ZZZ_i
+            ai = mul(ai, p.ZZZ);
+            F zi = mul(zi3, p.ZZ);            // 1 / Z
+            F zi2 = sqr(zi);
+            r.x = from_mont(mul(p.X, zi2));
+            r.y = from_mont(mul(p.Y, zi3));
+        }
+        out[i] = r;
+    }
+}
+
+template <class F, class HF>
+static int build_fixed_table(vsp_ctx *ctx, const Affine<HF> &gen, DevBuf &dst) {
+    if (dst.p) return VSP_OK;
+    std::vector<XYZZ<HF>> tj((size_t)FB_WINDOWS * FB_ENTRIES);
+    XYZZ<HF> wb = xyzz_from_affine(gen);
+    for (int w = 0; w < FB_WINDOWS; w++) {
+        XYZZ<HF> acc = wb;
+        for (int e = 0; e < FB_ENTRIES; e++) { tj[(size_t)w * FB_ENTRIES + e] = acc; xyzz_add(acc, wb); }
+        wb = acc;
+    }
+    // batch to affine on the host
+    size_t cnt = tj.size();
+    std::vector<HF> pre(cnt);
+    HF acc = HF::one();
+    for (size_t i = 0; i < cnt; i++) { pre[i] = acc; acc = mul(acc, tj[i].ZZZ); }
+    HF ai = inv(acc);
+    std::vector<Affine<HF>> ta(cnt);
+    for (size_t i = cnt; i-- > 0;) {
+        HF zi3 = mul(ai, pre[i]); ai = mul(ai, tj[i].ZZZ);
+        HF zi = mul(zi3, tj[i].ZZ), zi2 = sqr(zi);
+        ta[i].x = mul(tj[i].X, zi2); ta[i].y = mul(tj[i].Y, zi3);
+    }
+    VSP_TRY(ensure(ctx, dst, cnt * sizeof(Affine<F>)));
+    VSP_HIP(hipMemcpyAsync(dst.p, ta.data(), cnt * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+
+static const uint64_t G1_GEN[12] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL,
+                                    0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
+static const uint64_t G2_GEN[24] = {0xd48056c8c121bdb8ULL, 0x0bac0326a805bbefULL, 0xb4510b647ae3d177ULL, 0xc6e47ad4fa403b02ULL, 0x260805272dc51051ULL, 0x024aa2b2f08f0a91ULL,
+                                    0xe5ac7d055d042b7eULL, 0x334cf11213945d57ULL, 0xb5da61bbdc7f5049ULL, 0x596bd0d09920b61aULL, 0x7dacd3a088274f65ULL, 0x13e02b6052719f60ULL,
+                                    0xe193548608b82801ULL, 0x923ac9cc3baca289ULL, 0x6d429a695160d12cULL, 0xadfd9baa8cbdd3a7ULL, 0x8cc9cdc6da2e351aULL, 0x0ce5d527727d6e11ULL,
+                                    0xaaa9075ff05f79beULL, 0x3f370d275cec1da1ULL, 0x267492ab572e99abULL, 0xcb3e287e85a763afULL, 0x32acd2b02bc28b99ULL, 0x0606c4a02ea734ccULL};
+
+template <class F, class HF>
+static int fixed_base_mul(vsp_ctx *ctx, const Affine<HF> &gen, DevBuf &table, const Fr *d_scalars, size_t n, void *d_out) {
+    if (!n) return VSP_OK;
+    VSP_TRY((build_fixed_table<F, HF>(ctx, gen, table)));
+    VSP_TRY(ensure(ctx, ctx->fb_tmp, n * sizeof(XYZZ<F>)));
+    VSP_TRY(ensure(ctx, ctx->fb_pre, n * sizeof(F)));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fixed_base<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const Affine<F> *)table.p, d_scalars, n, (XYZZ<F> *)ctx->fb_tmp.p);
+    VSP_LAUNCH_CHECK();
+    size_t chunks = (n + BA_CHUNK - 1) / BA_CHUNK;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_batch_affine<F>), dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, ctx->stream,
+                       (const XYZZ<F> *)ctx->fb_tmp.p, n, (F *)ctx->fb_pre.p, (Affine<F> *)d_out);
+    VSP_LAUNCH_CHECK();
+    return VSP_OK;
+}
+int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out) {
+    return fixed_base_mul<Fp, HFp>(ctx, host_load_g1(G1_GEN), ctx->fb_g1, d_scalars, n, d_out);
+}
+int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out) {
+    return fixed_base_mul<Fp2, HFp2>(ctx, host_load_g2(G2_GEN), ctx->fb_g2, d_scalars, n, d_out);
+}
+
+}  // namespace vsp
+
+using namespace vsp;
+
+// ------------------------------------------------------------------------------------------------ C ABI: r1cs / pk / prove
+extern "C" {
+
+vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_inputs, size_t num_vars,
+                          const uint32_t *row_ptr_a, const uint32_t *col_a, const uint64_t *coef_a,
+                          const uint32_t *row_ptr_b, const uint32_t *col_b, const uint64_t *coef_b,
+                          const uint32_t *row_ptr_c, const uint32_t *col_c, const uint64_t *coef_c) {
+    if (!ctx) return nullptr;
+    if (!row_ptr_a || !row_ptr_b || !row_ptr_c || num_inputs > num_vars) { set_error(ctx, VSP_ERR_ARG, "r1cs_upload: bad argument"); return nullptr; }
+    hipSetDevice(ctx->device);
+    vsp_r1cs *cs = new vsp_r1cs();
+    cs->num_constraints = num_constraints; cs->num_inputs = num_inputs; cs->num_vars = num_vars;
+    cs->log_m = ceil_log2(num_constraints + num_inputs + 1);
+    const uint32_t *rp[3] = {row_ptr_a, row_ptr_b, row_ptr_c}, *ci[3] = {col_a, col_b, col_c};
+    const uint64_t *co[3] = {coef_a, coef_b, coef_c};
+    for (int m = 0; m < 3; m++) {
+        size_t nnz = rp[m][num_constraints];
+        for (size_t e = 0; e < nnz; e++) if (ci[m][e] > num_vars) { set_error(ctx, VSP_ERR_ARG, "r1cs_upload: column out of range"); vsp_r1cs_free(ctx, cs); return nullptr; }
+        bool ok = hipMalloc((void **)&cs->rp[m], (num_constraints + 1) * 4) == hipSuccess &&
+                  hipMalloc((void **)&cs->ci[m], (nnz ? nnz : 1) * 4) == hipSuccess &&
+                  hipMalloc(&cs->co[m], (nnz ? nnz : 1) * sizeof(Fr)) == hipSuccess;
+        if (!ok) { set_error(ctx, VSP_ERR_NOMEM, "r1cs_upload: hipMalloc"); vsp_r1cs_free(ctx, cs); return nullptr; }
+        hipMemcpyAsync(cs->rp[m], rp[m], (num_constraints + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(cs->ci[m], ci[m], nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(cs->co[m], co[m], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)cs->co[m], nnz);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error(ctx, VSP_ERR_HIP, "r1cs_upload: sync"); vsp_r1cs_free(ctx, cs); return nullptr; }
+    return cs;
+}
+
+void vsp_r1cs_free(vsp_ctx *ctx, vsp_r1cs *cs) {
+    if (!cs) return;
+    if (ctx) hipSetDevice(ctx->device);
+    for (int m = 0; m < 3; m++) { if (cs->rp[m]) hipFree(cs->rp[m]); if (cs->ci[m]) hipFree(cs->ci[m]); if (cs->co[m]) hipFree(cs->co[m]); }
+    delete cs;
+}
+
+vsp_pk *vsp_pk_create(vsp_ctx *ctx, const uint64_t alpha_g1[12], const uint64_t beta_g1[12], const uint64_t beta_g2[24],
+                      const uint64_t delta_g1[12], const uint64_t delta_g2[24],
+                      const vsp_bases *A_query, const vsp_bases *B_query_g1, const vsp_bases *B_query_g2,
+                      const vsp_bases *H_query, const vsp_bases *L_query) {
+    if (!ctx) return nullptr;
+    if (!alpha_g1 || !beta_g1 || !beta_g2 || !delta_g1 || !delta_g2 || !A_query || !B_query_g1 || !B_query_g2 || !H_query || !L_query ||
+        A_query->group != 1 || B_query_g1->group != 1 || B_query_g2->group != 2 || H_query->group != 1 || L_query->group != 1) {
+        set_error(ctx, VSP_ERR_ARG, "pk_create: bad argument"); return nullptr;
+    }
+    vsp_pk *pk = new vsp_pk();
+    pk->alpha_g1 = host_load_g1(alpha_g1); pk->beta_g1 = host_load_g1(beta_g1); pk->delta_g1 = host_load_g1(delta_g1);
+    pk->beta_g2 = host_load_g2(beta_g2); pk->delta_g2 = host_load_g2(delta_g2);
+    pk->A = A_query; pk->B1 = B_query_g1; pk->B2 = B_query_g2; pk->H = H_query; pk->L = L_query;
+    return pk;
+}
+void vsp_pk_free(vsp_ctx *, vsp_pk *pk) { delete pk; }
+
+int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
+                      const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
+                      uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!cs || !pk || !witness || !r || !s) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
+    const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints;
+    const unsigned lm = cs->log_m; const size_t m = (size_t)1 << lm;
+    if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
+        return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
+    VSP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // z = (1, witness) canonical on device
+    VSP_TRY(ensure(ctx, ctx->pr_z, (nv + 1) * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_a, m * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_b, m * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_c, m * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_h, m * sizeof(Fr)));
+    Fr *dz = (Fr *)ctx->pr_z.p, *dA = (Fr *)ctx->pr_a.p, *dB = (Fr *)ctx->pr_b.p, *dC = (Fr *)ctx->pr_c.p, *dH = (Fr *)ctx->pr_h.p;
+    const uint64_t one4[4] = {1, 0, 0, 0};
+    VSP_HIP(hipMemcpyAsync(dz, one4, 32, hipMemcpyHostToDevice, st));
+    VSP_HIP(hipMemcpyAsync(dz + 1, witness, nv * 32, hipMemcpyHostToDevice, st));
+    // evaluation vectors (witness_map part 1): A z, B z, C z, plus the rows "input_i * 0 = 0" in A
+    VSP_HIP(hipMemsetAsync(dA, 0, m * sizeof(Fr), st));
+    VSP_HIP(hipMemsetAsync(dB, 0, m * sizeof(Fr), st));
+    VSP_HIP(hipMemsetAsync(dC, 0, m * sizeof(Fr), st));
+    Fr *outs[3] = {dA, dB, dC};
+    if (nc) for (int k = 0; k < 3; k++) {
+        hipLaunchKernelGGL(k_csr_matvec, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, (const uint32_t *)cs->rp[k], (const uint32_t *)cs->ci[k],
+                           (const Fr *)cs->co[k], (const Fr *)dz, nc, outs[k]);
+        VSP_LAUNCH_CHECK();
+    }
+    VSP_HIP(hipMemcpyAsync(dA + nc, dz, (ni + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+    // the five multi-exponentiations
+    XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
+    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->A->d, dz, nv + 1, &eA));
+    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->B1->d, dz, nv + 1, &eB1));
+    VSP_TRY(msm_g2_device(ctx, (const G2Affine *)pk->B2->d, dz, nv + 1, &eB2));
+    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->H->d, dH, m - 1, &eH));
+    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->L->d, dz + ni + 1, nv - ni, &eL));
+    // assembly on the host: a dozen group operations
+    XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
+    XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
+    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); { XYZZ<HFp> t = xyzz_mul_scalar(dj, r, 255); xyzz_add(gA, t); }
+    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); { XYZZ<HFp> t = xyzz_mul_scalar(dj, s, 255); xyzz_add(gB1, t); }
+    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); { XYZZ<HFp2> t = xyzz_mul_scalar(dj2, s, 255); xyzz_add(gB2, t); }
+    HFr rr = host_load_canon<HFr>(r), ss = host_load_canon<HFr>(s);
+    uint64_t rs4[4]; host_store_canon(rs4, mul(rr, ss));
+    XYZZ<HFp> gC = eH; xyzz_add(gC, eL);
+    { XYZZ<HFp> t = xyzz_mul_scalar(gA, s, 255); xyzz_add(gC, t); }
+    { XYZZ<HFp> t = xyzz_mul_scalar(gB1, r, 255); xyzz_add(gC, t); }
+    { XYZZ<HFp> t = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255)); xyzz_add(gC, t); }
+    if (saver_P1 && saver_r_enc) { XYZZ<HFp> t = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255); xyzz_add(gC, t); }
+    Affine<HFp> a = xyzz_to_affine(gA), c = xyzz_to_affine(gC);
+    Affine<HFp2> b = xyzz_to_affine(gB2);
+    uint64_t A12[12], B24[24], C12[12];
+    host_store_g1(A12, a); host_store_g2(B24, b); host_store_g1(C12, c);
+    if (A_out) memcpy(A_out, A12, sizeof A12);
+    if (B_out) memcpy(B_out, B24, sizeof B24);
+    if (C_out) memcpy(C_out, C12, sizeof C12);
+    if (proof_out) { vsp_g1_compress(A12, proof_out); vsp_g2_compress(B24, proof_out + 48); vsp_g1_compress(C12, proof_out + 144); }
+    return VSP_OK;
+}
+
+}  // extern "C"
