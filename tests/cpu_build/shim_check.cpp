@@ -1,0 +1,37 @@
+// Compile-and-link check of the C++ shims against a stand-in value type defined HERE (crypto3 headers are absent,
+// SURVEY.md F1/F3).  With a GPU it also runs: 2*G via multiexp and an fft/inverse_fft round trip.
+#include <cstdio>
+#include <cstring>
+#include "../../include/vsp/evaluation_domain.hpp"
+#include "../../include/vsp/multiexp.hpp"
+
+struct Fr4 { std::uint64_t l[4]; bool operator==(const Fr4 &o) const { return !memcmp(l, o.l, 32); } };
+struct Fp6 { std::uint64_t l[6]; };
+struct G1pt { Fp6 x, y; bool inf; };
+namespace vsp {
+template <> struct limb_traits<Fr4> { static constexpr std::size_t limbs = 4; static void to_limbs(const Fr4 &v, std::uint64_t *o) { memcpy(o, v.l, 32); } static Fr4 from_limbs(const std::uint64_t *i) { Fr4 r; memcpy(r.l, i, 32); return r; } };
+template <> struct limb_traits<Fp6> { static constexpr std::size_t limbs = 6; static void to_limbs(const Fp6 &v, std::uint64_t *o) { memcpy(o, v.l, 48); } static Fp6 from_limbs(const std::uint64_t *i) { Fp6 r; memcpy(r.l, i, 48); return r; } };
+template <> struct point_traits<G1pt> {
+    using field_type = Fp6; static constexpr int group = 1;
+    static bool is_zero(const G1pt &p) { return p.inf; }
+    static void to_affine_xy(const G1pt &p, Fp6 &x, Fp6 &y) { x = p.x; y = p.y; }
+    static G1pt from_affine_xy(const Fp6 &x, const Fp6 &y) { return G1pt{x, y, false}; }
+    static G1pt zero() { G1pt p; memset(&p, 0, sizeof p); p.inf = true; return p; }
+};
+}
+int main() {
+    G1pt g{{{0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL}},
+           {{0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL}}, false};
+    std::vector<G1pt> bases{g, g};
+    std::vector<Fr4> scalars{Fr4{{1, 0, 0, 0}}, Fr4{{1, 0, 0, 0}}};
+    try {
+        G1pt r = vsp::multiexp<vsp::policies::multiexp_method_BDLO12>(bases.begin(), bases.end(), scalars.begin(), scalars.end(), 1);
+        std::printf("2G.x[0] = %016llx\n", (unsigned long long)r.x.l[0]);
+        auto dom = vsp::make_evaluation_domain<Fr4>(5);
+        std::vector<Fr4> a(dom->m);
+        for (std::size_t i = 0; i < a.size(); i++) a[i] = Fr4{{i + 1, 0, 0, 0}};
+        auto b = a; dom->fft(b); dom->inverse_fft(b);
+        std::printf("roundtrip %s\n", b == a ? "ok" : "MISMATCH");
+        return b == a ? 0 : 1;
+    } catch (const std::exception &e) { std::printf("no GPU path: %s\n", e.what()); return 77; }
+}

@@ -65,3 +65,13 @@ def test_product_never_imports_the_oracle():
     for f in os.listdir(os.path.join(ROOT, "include")):
         text = open(os.path.join(ROOT, "include", f), errors="ignore").read() if os.path.isfile(os.path.join(ROOT, "include", f)) else ""
         assert "vsp_ref" not in text
+
+
+def test_cpp_shims_compile_and_link(tmp_path):
+    """include/vsp/{multiexp,evaluation_domain}.hpp compile against a stand-in value type and link to the library."""
+    import subprocess
+    exe = str(tmp_path / "shim_check")
+    libdir = os.path.join(ROOT, "vote_saver_protocol_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpu_build", "shim_check.cpp"), "-o", exe,
+                           "-L", libdir, "-lvsp_hip", "-Wl,-rpath," + libdir])
+    assert os.path.exists(exe)
