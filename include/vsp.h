@@ -145,6 +145,12 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
 int vsp_fixed_base_mul_g1(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out /* n x 12 u64 */);
 int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out /* n x 24 u64 */);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------
+ * Elementwise field arithmetic on the GPU over n canonical values (host buffers): field 0 = Fp (6 limbs),
+ * 1 = Fr (4 limbs); op 0 mul, 1 add, 2 sub, 3 sqr(a), 4 canonical-times-Montgomery product, 5 inverse(a).
+ * Lets the tests check the kernels' Montgomery arithmetic directly against known-answer vectors. */
+int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+
 /* ---- wire format helpers (host only, tiny) --------------------------------------------------- */
 int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]);
 int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]);

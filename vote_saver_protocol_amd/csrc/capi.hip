@@ -50,11 +50,47 @@ template <> int finish_affine<Fp2, HFp2>(const XYZZ<HFp2> &acc, uint64_t *out_af
     return VSP_OK;
 }
 
+// elementwise field operations on canonical values (diagnostic entry point vsp_selftest_field)
+template <class F> __global__ void k_selftest_field(int op, const F *a, const F *b, F *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = a[i], y = b[i], r;
+    switch (op) {
+        case 0: r = from_mont(mul(to_mont(x), to_mont(y))); break;
+        case 1: r = add(x, y); break;
+        case 2: r = sub(x, y); break;
+        case 3: r = from_mont(sqr(to_mont(x))); break;
+        case 4: r = mul(x, to_mont(y)); break;          // canonical x Montgomery -> canonical (the NTT butterfly product)
+        default: r = from_mont(inv(to_mont(x))); break;
+    }
+    out[i] = r;
+}
+
 }  // namespace vsp
 
 using namespace vsp;
 
 extern "C" {
+
+int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 5) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t esz = field == 0 ? sizeof(Fp) : sizeof(Fr);
+    DevBuf da, db, dc;
+    int rc = ensure(ctx, da, n * esz); if (rc == VSP_OK) rc = ensure(ctx, db, n * esz); if (rc == VSP_OK) rc = ensure(ctx, dc, n * esz);
+    if (rc == VSP_OK) {
+        hipMemcpyAsync(da.p, a, n * esz, hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(db.p, b, n * esz, hipMemcpyHostToDevice, ctx->stream);
+        unsigned blocks = (unsigned)((n + 63) / 64);
+        if (field == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fp>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fr>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fr *)da.p, (const Fr *)db.p, (Fr *)dc.p, n);
+        hipMemcpyAsync(out, dc.p, n * esz, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "selftest: kernel failed");
+    }
+    free_buf(da); free_buf(db); free_buf(dc);
+    return rc;
+}
 
 vsp_ctx *vsp_create(int device_ordinal) {
     int count = 0;
