@@ -1,47 +1,61 @@
 #!/usr/bin/env python3
-"""Generates vote_saver_protocol_amd/csrc/mont_asm_gfx950.h: the Montgomery product of the device field types as
-ONE inline-asm statement per field (finely integrated product scanning / Comba).  One statement means no
-compiler-inserted boundary padding (an s_nop follows every ;;#ASMEND) and no per-product register shuffling:
+"""Generates vote_saver_protocol_amd/csrc/mont_asm_gfx950.h: the Montgomery product of the device field types
+(Fp: 12 x 32-bit limbs, Fr: 8) for gfx950 as a hand-laid-out routine with a PRIVATE calling convention.
 
-    per limb product:  v_mad_u64_u32 (acc += x*y, carry-out in VCC)  +  v_addc_co_u32 (carry into the third word)
-    per column:        one v_mov_b32 (high word becomes the next column's low word) and one v_mul_lo_u32 (m_k)
+Algorithm: finely integrated product scanning (Comba).  Per limb product exactly one v_mad_u64_u32 (64-bit
+multiply-accumulate, carry-out in VCC) and one v_addc_co_u32 (carry into the third accumulator word); per column one
+v_mov_b32 and one v_mul_lo_u32 (m_k); the final conditional subtraction runs in the dead operand registers.
+Two 64-bit accumulator pairs alternate between columns: while a column sums into one pair its carries collect in the
+HIGH register of the other pair -- exactly where the next column needs them.
 
-Two 64-bit accumulator pairs alternate between columns (fixed caller-saved registers v[32:33], v[34:35], because
-inline asm cannot name the halves of a 64-bit operand): while a column sums into one pair, its carries collect in
-the HIGH register of the other pair -- exactly where the next column needs them.
+Why a private convention: under the standard AMDGPU function ABI only every other block of 8 VGPRs above v40 survives a
+call, so a kernel with ~100 live limbs around each product needed 243 VGPRs (2 waves/SIMD), and aggregate operands
+beyond 16 dwords travel through scratch.  Here the routine body lives behind a label inside a never-called holder
+function, uses ONLY v0..v(3N+3), s0..s12, s[30:31], VCC, and is entered with s_swappc_b64 from an inline-asm
+trampoline whose operand constraints pin a -> v0.., b -> vN.., r <- v2N.. and whose clobber list is exact.  The
+compiler keeps every other live value wherever it likes, with no save/restore and no memory traffic.
+
+Register map (N limbs):  a: v0..vN-1   b: vN..v2N-1   m / r: v2N..v3N-1   accumulators: v[3N:3N+1], v[3N+2:3N+3]
+                         s0..sN-1 = modulus limbs, s12 = -p^-1 mod 2^32, s[30:31] = return address
 
 Run:  python tools/gen_mont_asm.py
 """
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vote_saver_protocol_amd", "csrc", "mont_asm_gfx950.h")
-PAIRS = [("v32", "v33", "v[32:33]"), ("v34", "v35", "v[34:35]")]
 
 
-def gen(name, N):
+def body(N):
+    A = lambda i: f"v{i}"
+    B = lambda i: f"v{N + i}"
+    M = lambda i: f"v{2 * N + i}"
+    Pm = lambda i: f"s{i}"
+    INV = "s12"
+    base = 3 * N
+    pairs = [(f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]"), (f"v{base + 2}", f"v{base + 3}", f"v[{base + 2}:{base + 3}]")]
     ins = []
     cur, oth = 0, 1
-    ins.append(f"v_mov_b32 {PAIRS[0][0]}, 0")
-    ins.append(f"v_mov_b32 {PAIRS[0][1]}, 0")
+    ins.append(f"v_mov_b32 {pairs[0][0]}, 0")
+    ins.append(f"v_mov_b32 {pairs[0][1]}, 0")
     for k in range(2 * N - 1):
-        lo_c, hi_c, pr_c = PAIRS[cur]
-        lo_o, hi_o, _ = PAIRS[oth]
+        lo_c, hi_c, pr_c = pairs[cur]
+        lo_o, hi_o, _ = pairs[oth]
         terms = []
         if k < N:
             for i in range(k):
-                terms.append((f"%[a{i}]", f"%[b{k - i}]"))
-                terms.append((f"%[m{i}]", f"%[p{k - i}]"))
-            terms.append((f"%[a{k}]", "%[b0]"))
+                terms.append((A(i), B(k - i)))
+                terms.append((M(i), Pm(k - i)))
+            terms.append((A(k), B(0)))
             terms.append(("MK", None))
         else:
             for i in range(k - N + 1, N):
-                terms.append((f"%[a{i}]", f"%[b{k - i}]"))
-                terms.append((f"%[m{i}]", f"%[p{k - i}]"))
+                terms.append((A(i), B(k - i)))
+                terms.append((M(i), Pm(k - i)))
         first = True
         for x, y in terms:
             if x == "MK":
-                ins.append(f"v_mul_lo_u32 %[m{k}], {lo_c}, %[inv]")
-                x, y = f"%[m{k}]", "%[p0]"
+                ins.append(f"v_mul_lo_u32 {M(k)}, {lo_c}, {INV}")
+                x, y = M(k), Pm(0)
             ins.append(f"v_mad_u64_u32 {pr_c}, vcc, {x}, {y}, {pr_c}")
             if first:
                 ins.append(f"v_addc_co_u32_e64 {hi_o}, vcc, 0, 0, vcc")
@@ -49,45 +63,67 @@ def gen(name, N):
             else:
                 ins.append(f"v_addc_co_u32 {hi_o}, vcc, 0, {hi_o}, vcc")
         if k >= N:
-            ins.append(f"v_mov_b32 %[m{k - N}], {lo_c}")      # m_j is dead from column N+j on: its register becomes r_j
+            ins.append(f"v_mov_b32 {M(k - N)}, {lo_c}")      # m_j is dead from column N+j on: its register becomes r_j
         ins.append(f"v_mov_b32 {lo_o}, {hi_c}")
         cur, oth = oth, cur
-    ins.append(f"v_mov_b32 %[m{N - 1}], {PAIRS[cur][0]}")
-    # final conditional subtraction r - p (a's registers are dead now and hold the difference)
-    # (an SGPR operand plus the VCC carry-in would be two constant-bus reads: the modulus goes through b's dead registers)
-    ins.append(f"v_subrev_co_u32 %[a0], vcc, %[p0], %[m0]")
+    ins.append(f"v_mov_b32 {M(N - 1)}, {pairs[cur][0]}")
+    # final conditional subtraction r - p in the dead a / b registers (SGPR + VCC carry-in would be two constant-bus reads)
+    ins.append(f"v_subrev_co_u32 {A(0)}, vcc, {Pm(0)}, {M(0)}")
     for i in range(1, N):
-        ins.append(f"v_mov_b32 %[b{i}], %[p{i}]")
-        ins.append(f"v_subb_co_u32 %[a{i}], vcc, %[m{i}], %[b{i}], vcc")
+        ins.append(f"v_mov_b32 {B(i)}, {Pm(i)}")
+        ins.append(f"v_subb_co_u32 {A(i)}, vcc, {M(i)}, {B(i)}, vcc")
     for i in range(N):
-        ins.append(f"v_cndmask_b32 %[m{i}], %[a{i}], %[m{i}], vcc")   # borrow -> keep r, else take r - p
-    body = "\n".join(f'        "{x}\\n\\t"' for x in ins)
-    outs = ", ".join([f'[m{i}] "=&v"(r[{i}])' for i in range(N)] + [f'[a{i}] "+v"(a[{i}])' for i in range(N)] +
-                     [f'[b{i}] "+v"(b[{i}])' for i in range(N)])
-    inps = ", ".join(
-                     [f'[p{i}] "s"(P::MOD[{i}])' for i in range(N)] + ['[inv] "s"(P::INV)'])
+        ins.append(f"v_cndmask_b32 {M(i)}, {A(i)}, {M(i)}, vcc")   # borrow -> keep r, else take r - p
+    return ins
+
+
+def gen(N):
+    ins = body(N)
     n_mad = sum(1 for x in ins if x.startswith("v_mad"))
-    return f'''// {name}: N = {N} limbs, {n_mad} v_mad_u64_u32, {len(ins)} instructions.  r = a*b*2^(-{32 * N}) mod p, fully reduced.
-// a[] and b[] are clobbered (their registers are the scratch of the final subtraction); 2N + N + 4 = {3 * N + 4} VGPRs in total.
-template <class P> __device__ __forceinline__ void mont_mul_asm_{N}(uint32_t *r, uint32_t *a, uint32_t *b) {{
+    label = f"vsp_mm_{N}"
+    lines = [f's_branch .Lvsp_mm_{N}_end', '.p2align 8', f'{label}:']
+    lines += [f's_mov_b32 s{i}, %[p{i}]' for i in range(N)]      # literal constants via "i" operands
+    lines += ['s_mov_b32 s12, %[inv]']
+    lines += ins + ['s_setpc_b64 s[30:31]', f'.Lvsp_mm_{N}_end:']
+    body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
+    consts = ", ".join([f'[p{i}] "i"(P::MOD[{i}])' for i in range(N)] + ['[inv] "i"(P::INV)'])
+    vclob = ", ".join(f'"v{i}"' for i in range(3 * N + 4))
+    sclob = ", ".join(f'"s{i}"' for i in range(13))
+    holder = f'''// ---- N = {N}: {n_mad} v_mad_u64_u32, {len(ins)} instructions, VGPRs v0..v{3 * N + 3} ----
+template <class P> __device__ __attribute__((noinline, used)) void mont_mul_holder_{N}() {{
     static_assert(P::N == {N}, "limb count");
-    asm(
-{body}
-        : {outs}
-        : {inps}
-        : "vcc", "v32", "v33", "v34", "v35");
+    asm volatile(
+{body_txt}
+        :
+        : {consts}
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclob});
 }}
 '''
+    outs = ", ".join([f'"={{v{2 * N + i}}}"(r[{i}])' for i in range(N)] + [f'"+{{v{i}}}"(a[{i}])' for i in range(N)] +
+                     [f'"+{{v{N + i}}}"(b[{i}])' for i in range(N)])
+    acc = ", ".join(f'"v{3 * N + i}"' for i in range(4))
+    call = f'''// r = a*b*2^(-{32 * N}) mod p, fully reduced.  a[] and b[] are clobbered.
+template <class P> __device__ __forceinline__ void mont_mul_asm_{N}(uint32_t *r, uint32_t *a, uint32_t *b) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, {label}@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, {label}@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outs}
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {acc});
+}}
+'''
+    return holder + "\n" + call
 
 
 def main():
-    text = '''// GENERATED by tools/gen_mont_asm.py -- do not edit.  Montgomery product for gfx950 as one asm statement per field.
+    text = '''// GENERATED by tools/gen_mont_asm.py -- do not edit.  See that file for the design notes.
 #pragma once
 #include <stdint.h>
 
 namespace vsp {
 
-''' + gen("Fp (BLS12-381 base field)", 12) + "\n" + gen("Fr (BLS12-381 scalar field)", 8) + "\n}  // namespace vsp\n"
+''' + gen(12) + "\n" + gen(8) + "\n}  // namespace vsp\n"
     open(OUT, "w").write(text)
     print("wrote", os.path.normpath(OUT))
 

@@ -51,7 +51,7 @@ template <> int finish_affine<Fp2, HFp2>(const XYZZ<HFp2> &acc, uint64_t *out_af
 }
 
 // elementwise field operations on canonical values (diagnostic entry point vsp_selftest_field)
-template <class F> __global__ void k_selftest_field(int op, const F *a, const F *b, F *out, size_t n) {
+template <class F> __global__ __launch_bounds__(64) void k_selftest_field(int op, const F *a, const F *b, F *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F x = a[i], y = b[i], r;
@@ -110,7 +110,7 @@ void vsp_destroy(vsp_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch,
                       &ctx->msm_cnt, &ctx->msm_off, &ctx->msm_cursor, &ctx->msm_nsub, &ctx->msm_suboff, &ctx->msm_blocksum, &ctx->msm_sorted,
-                      &ctx->msm_heavy, &ctx->msm_counters, &ctx->msm_buckets, &ctx->msm_partials, &ctx->msm_dims, &ctx->msm_winres,
+                      &ctx->msm_heavy, &ctx->msm_counters, &ctx->msm_digits, &ctx->msm_blockhist, &ctx->msm_partbucket, &ctx->msm_perm, &ctx->msm_sizehist, &ctx->msm_buckets, &ctx->msm_partials, &ctx->msm_dims, &ctx->msm_winres,
                       &ctx->msm_scalars, &ctx->msm_tmp_bases, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
                       &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
     for (DevBuf *b : bufs) free_buf(*b);

@@ -43,6 +43,7 @@ struct vsp_ctx {
     vsp::DevBuf ntt_scratch;
     // MSM workspaces (grow only)
     vsp::DevBuf msm_cnt, msm_off, msm_cursor, msm_nsub, msm_suboff, msm_blocksum, msm_sorted, msm_heavy, msm_counters;
+    vsp::DevBuf msm_digits, msm_blockhist, msm_partbucket, msm_perm, msm_sizehist;
     vsp::DevBuf msm_buckets, msm_partials, msm_dims, msm_winres, msm_scalars, msm_tmp_bases;
     // fixed-base tables (generator multiples), built lazily
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;

@@ -177,37 +177,18 @@ template <class P> VSP_HD Mont<P> mul_cios(const Mont<P> &a, const Mont<P> &b) {
 }  // namespace vsp
 #include "mont_asm_gfx950.h"
 namespace vsp {
-// gfx950: finely integrated product scanning (Comba), generated as ONE asm statement per field by
-// tools/gen_mont_asm.py: exactly one v_mad_u64_u32 + one v_addc_co_u32 per limb product -- measured issue cost
-// 6.6 + 4.6 cycles per wave against ~21 cycles per product for the mov/add sequence the compiler derives from the
-// portable CIOS form (profiles/r1_ubench_valu.txt).
-// Operands and result travel as uint32 vectors: vector arguments are always passed in VGPRs (aggregates beyond 16
-// dwords would go through scratch), and the body needs only the caller-saved registers v0-v39, so a call costs no
-// memory traffic at all.
-template <int N> struct LimbVec;
-template <> struct LimbVec<12> { typedef uint32_t T __attribute__((ext_vector_type(12))); };
-template <> struct LimbVec<8> { typedef uint32_t T __attribute__((ext_vector_type(8))); };
-template <class P> __device__ __attribute__((noinline)) typename LimbVec<P::N>::T mul_dev(typename LimbVec<P::N>::T av, typename LimbVec<P::N>::T bv) {
-    constexpr int N = P::N;
-    uint32_t a[N], b[N], r[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) { a[i] = av[i]; b[i] = bv[i]; }
-    if constexpr (N == 12) mont_mul_asm_12<P>(r, a, b);
-    else mont_mul_asm_8<P>(r, a, b);
-    typename LimbVec<N>::T rv;
-#pragma unroll
-    for (int i = 0; i < N; i++) rv[i] = r[i];
-    return rv;
-}
+// gfx950: finely integrated product scanning (Comba) as a generated asm routine with a private calling
+// convention (tools/gen_mont_asm.py): exactly one v_mad_u64_u32 + one v_addc_co_u32 per limb product -- measured
+// issue cost 6.6 + 4.6 cycles per wave against ~21 cycles per product for the mov/add sequence the compiler derives
+// from the portable CIOS form (profiles/r1_ubench_valu.txt) -- entered with s_swappc_b64, clobbering only v0..v39.
 template <class P> __device__ __forceinline__ Mont<P> mul_comba(const Mont<P> &a, const Mont<P> &b) {
     constexpr int N = P::N;
-    typename LimbVec<N>::T av, bv;
-#pragma unroll
-    for (int i = 0; i < N; i++) { av[i] = a.l[i]; bv[i] = b.l[i]; }
-    typename LimbVec<N>::T rv = mul_dev<P>(av, bv);
+    uint32_t x[N], y[N];
     Mont<P> r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.l[i] = rv[i];
+    for (int i = 0; i < N; i++) { x[i] = a.l[i]; y[i] = b.l[i]; }
+    if constexpr (N == 12) { mont_mul_asm_12<P>(r.l, x, y); (void)&mont_mul_holder_12<P>; }
+    else { mont_mul_asm_8<P>(r.l, x, y); (void)&mont_mul_holder_8<P>; }
     return r;
 }
 #endif

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const Fr *__restrict__
 }
 
 // T[j] = A[j & 2047] * B[j >> 11]  (all Montgomery)
-__global__ void k_fill_twiddles(Fr *T, const Fr *A, const Fr *B, size_t count) {
+__global__ __launch_bounds__(256) void k_fill_twiddles(Fr *T, const Fr *A, const Fr *B, size_t count) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < count) T[j] = mul(A[j & ((1u << PW_LOG) - 1u)], B[j >> PW_LOG]);
 }
@@ -134,7 +134,7 @@ __global__ void k_fill_twiddles(Fr *T, const Fr *A, const Fr *B, size_t count) {
 // h[i] = montmul(a[i], b[i]) - montmul(c[i], 1) = (a*b - c) / R  (canonical a, b, c).  The missing
 // factor R, the divide_by_z_on_coset constant 1/Z(g) and m^-1 are folded into the scale constant of
 // the inverse coset transform that follows, so this stays at two products per element.
-__global__ void k_ab_minus_c(Fr *h, const Fr *a, const Fr *b, const Fr *c, size_t n) {
+__global__ __launch_bounds__(256) void k_ab_minus_c(Fr *h, const Fr *a, const Fr *b, const Fr *c, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) h[i] = sub(mul(a[i], b[i]), mul(c[i], Fr::raw_one()));
 }

@@ -14,14 +14,14 @@
 namespace vsp {
 
 // ---- sparse mat-vec: out[row] = sum_e coef[e] * z[col[e]],  z canonical, coef Montgomery -> canonical out
-__global__ void k_csr_matvec(const uint32_t *rp, const uint32_t *ci, const Fr *co, const Fr *z, size_t rows, Fr *out) {
+__global__ __launch_bounds__(256) void k_csr_matvec(const uint32_t *rp, const uint32_t *ci, const Fr *co, const Fr *z, size_t rows, Fr *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     Fr acc = Fr::zero();
     for (uint32_t e = rp[i]; e < rp[i + 1]; e++) acc = add(acc, mul(z[ci[e]], co[e]));
     out[i] = acc;
 }
-__global__ void k_fr_to_mont(Fr *a, size_t n) {
+__global__ __launch_bounds__(256) void k_fr_to_mont(Fr *a, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = to_mont(a[i]);
 }
@@ -30,7 +30,7 @@ __global__ void k_fr_to_mont(Fr *a, size_t n) {
 static constexpr int FB_WINDOWS = 32, FB_ENTRIES = 255;
 
 template <class F>
-__global__ void k_fixed_base(const Affine<F> *table, const Fr *scalars, size_t n, XYZZ<F> *out) {
+__global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, const Fr *scalars, size_t n, XYZZ<F> *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *kb = (const uint8_t *)scalars[i].l;
@@ -46,7 +46,7 @@ __global__ void k_fixed_base(const Affine<F> *table, const Fr *scalars, size_t n
 // (Montgomery's trick, prefix products kept in global scratch `pre`)
 static constexpr unsigned BA_CHUNK = 32;
 template <class F>
-__global__ void k_batch_affine(const XYZZ<F> *in, size_t n, F *pre, Affine<F> *out) {
+__global__ __launch_bounds__(64) void k_batch_affine(const XYZZ<F> *in, size_t n, F *pre, Affine<F> *out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t b = t * BA_CHUNK, e = b + BA_CHUNK < n ? b + BA_CHUNK : n;
     if (b >= n) return;
