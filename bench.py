@@ -50,6 +50,72 @@ def limbs(v, n):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
 
 
+def bench_prove(ctx, v, cref, o, dev, torch, log_m):
+    """BASELINE config 4: full r1cs_gg_ppzksnark prove on a synthetic satisfiable R1CS filling a 2^log_m domain
+    (90 % boolean wires, 30 public inputs).  The proving key is built on the GPU (generator batch
+    exponentiation), the proof is verified with the oracle's pairing, the CPU leg is the oracle's serial prover."""
+    import pairing as pg
+    ni = 30
+    nc = (1 << log_m) - ni - 2
+    gen = o.splitmix64(5)
+    cs, wit = cref.R1CS.synth(nc, ni, 4)
+    tox_i = [o.rand_fr(gen) for _ in range(5)]
+    tox = np.array([o.int_to_limbs(x, 4) for x in tox_i], dtype=np.uint64)
+    t0 = time.perf_counter()
+    ks = cs.key_scalars(tox)
+    queries = []
+    for name, group in (("A", 1), ("B", 1), ("B", 2), ("H", 1), ("L", 1)):
+        d_sc = torch.from_numpy(ks[name].view(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        d_pts = v.fixed_base_mul(ctx, d_sc, ks[name].shape[0], group)
+        queries.append(ctx.bases_from_device(d_pts, ks[name].shape[0], group))
+        ctx.dfree(d_pts)
+    G1l = np.array(o.g1_to_limbs(o.G1.gen), dtype=np.uint64); G2l = np.array(o.g2_to_limbs(o.G2.gen), dtype=np.uint64)
+    alpha_g1 = cref.g1_mul(G1l, tox[1]); beta_g1 = cref.g1_mul(G1l, tox[2]); delta_g1 = cref.g1_mul(G1l, tox[4])
+    beta_g2 = cref.g2_mul(G2l, tox[2]); delta_g2 = cref.g2_mul(G2l, tox[4]); gamma_g2 = cref.g2_mul(G2l, tox[3])
+    pk = v.ProvingKey(ctx, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, *queries)
+    A, B, Cm = cs.export()
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
+    setup_s = time.perf_counter() - t0
+    r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
+    pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)          # warm-up (twiddles, workspaces)
+    reps = 5
+    ctx.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)
+    dt = (time.perf_counter() - t0) / reps
+    phases = {k: ctx.stat("prove_" + k + "_ms") / reps for k in ("launch", "host_overlap", "wait", "assembly")}
+    vk = dict(alpha_g1=o.g1_from_limbs(alpha_g1), beta_g2=o.g2_from_limbs(beta_g2), gamma_g2=o.g2_from_limbs(gamma_g2),
+              delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in cref.g1_batch_mul_gen(ks["ABC"])])
+    pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
+    ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
+    out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
+           f"prove_2p{log_m}_constraints": nc, f"prove_2p{log_m}_gpu_keygen_setup_s": setup_s,
+           f"prove_2p{log_m}_phase_ms": phases}
+    pk.free(); dcs.free(); [q.free() for q in queries]; cs.free()
+    # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
+    lg_s = 14
+    nc_s = (1 << lg_s) - ni - 2
+    cs2, wit2 = cref.R1CS.synth(nc_s, ni, 4)
+    kp = cref.Keypair(cs2, tox)
+    t0 = time.perf_counter()
+    eA, eB, eC = kp.prove(wit2, r, s_)
+    cpu_dt = time.perf_counter() - t0
+    q2 = [ctx.upload_bases(kp.part(nm), g) for nm, g in (("A_query", 1), ("B_query_g1", 1), ("B_query_g2", 2), ("H_query", 1), ("L_query", 1))]
+    pk2 = v.ProvingKey(ctx, kp.part("alpha_g1")[0], kp.part("beta_g1")[0], kp.part("beta_g2")[0], kp.part("delta_g1")[0], kp.part("delta_g2")[0], *q2)
+    A2, B2, C2 = cs2.export()
+    dcs2 = v.R1CS(ctx, nc_s, ni, cs2.num_vars, A2, B2, C2)
+    v.groth16_prove(ctx, dcs2, pk2, wit2, r, s_)
+    t0 = time.perf_counter()
+    gA, gB, gC, _ = v.groth16_prove(ctx, dcs2, pk2, wit2, r, s_)
+    gpu_dt = time.perf_counter() - t0
+    out.update({f"prove_2p{lg_s}_cpu_oracle_s": cpu_dt, f"prove_2p{lg_s}_gpu_ms": gpu_dt * 1e3,
+                f"prove_2p{lg_s}_bit_exact_vs_cpu": bool(np.array_equal(gA, eA) and np.array_equal(gB, eB) and np.array_equal(gC, eC))})
+    pk2.free(); dcs2.free(); [q.free() for q in q2]; kp.free(); cs2.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +125,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary NTT / G2 measurements")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
+    ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
     args = ap.parse_args()
 
     import torch
@@ -98,8 +166,7 @@ def main():
     rec_dev = torch.zeros(18, dtype=torch.int64, device=dev)
     all_dev = torch.zeros(18 * world, dtype=torch.int64, device=dev)
 
-    def step():
-        rec = bases.msm_jacobian(d_s)                       # the rank's shard: full Pippenger pipeline
+    def exchange(rec):
         if world > 1:                                       # exchange step: 144-byte Jacobian record per rank
             rec_dev.copy_(torch.from_numpy(rec.view(np.int64)))
             dist.all_gather_into_tensor(all_dev, rec_dev)
@@ -113,17 +180,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        result = step()
+    def run_steps(k_steps):
+        """k_steps full MSMs, software-pipelined two deep over work slots 0/1 (each on its own stream): the sort and
+        bucket accumulation of step k+1 overlap the latency-bound bucket reduction and host Horner of step k."""
+        res = None
+        bases.msm_launch(0, d_s)
+        for k in range(1, k_steps):
+            bases.msm_launch(k & 1, d_s)
+            res = exchange(bases.msm_finish_jacobian((k - 1) & 1))
+        return exchange(bases.msm_finish_jacobian((k_steps - 1) & 1))
+
+    if args.warmup:
+        result = run_steps(args.warmup)
     ctx.stats_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
+    result = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     accum_ms = ctx.stat("msm_accum_ms")
     accum_launches = ctx.stat("msm_accum_launches")
+    main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,6 +270,9 @@ def main():
             extras["g2_msm_2p18_points_per_s"] = n2 / dtg
             b2.free()
 
+        if world == 1 and not args.no_prove:
+            extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n))
+
     ctx.dfree(d_bases_canon)
     total_points = n * world * args.steps
     value = total_points / elapsed
@@ -214,7 +294,7 @@ def main():
         "config": {"workload": f"2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU, bases k_i*G, uniform scalars, "
                                f"resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
                                "RCCL all-gather of Jacobian partial sums + fold",
-                   "points_per_gpu": n, "window_bits": int(ctx.stat("msm_window_bits")), "windows": int(ctx.stat("msm_windows"))},
+                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w},
         "verified_bit_exact": verified,
         "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -92,6 +92,14 @@ int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t 
  * buffer -- the fixed-size record ranks exchange in the sharded multi-GPU MSM. */
 int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n,
                               const void *d_scalars, uint64_t *out_jacobian);
+/* Pipelined form: vsp_msm_launch enqueues the whole multi-exponentiation on work slot `slot` (0..5; slot 0 runs on the
+ * context's stream, the others on streams of their own) and returns once the GPU work is queued; vsp_msm_finish_jacobian
+ * waits for that slot and returns the Jacobian record.  Several slots may be in flight, so the latency-bound tail of one
+ * multi-exponentiation overlaps the bulk of the next (the prover runs its five this way).  The scalars must be complete in
+ * device memory before the launch and must not change until the finish. */
+int vsp_msm_launch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars);
+int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian);
+
 /* Fold `count` Jacobian records (host, canonical) into one affine point; group: 1 = G1, 2 = G2. */
 int vsp_fold_jacobian(vsp_ctx *ctx, int group, const uint64_t *records, size_t count,
                       uint64_t *out_affine, int *out_is_inf);

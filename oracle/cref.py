@@ -159,6 +159,15 @@ class R1CS:
         lib().ref_witness_map(self.h, _p(_u64(witness)), _p(H), None, None, None)
         return H
 
+    def key_scalars(self, toxic):
+        """The generator's exponents (canonical Fr) for (A_query, B_query, H_query, L_query, gamma_ABC)."""
+        m = 1 << self.log_m
+        nv, ni = self.num_vars, self.num_inputs
+        A = np.zeros((nv + 1, 4), np.uint64); B = np.zeros((nv + 1, 4), np.uint64)
+        H = np.zeros((m - 1, 4), np.uint64); Lq = np.zeros((nv - ni, 4), np.uint64); ABC = np.zeros((ni + 1, 4), np.uint64)
+        lib().ref_groth16_key_scalars(self.h, _p(_u64(toxic)), _p(A), _p(B), _p(H), _p(Lq), _p(ABC))
+        return dict(A=A, B=B, H=H, L=Lq, ABC=ABC)
+
     def free(self):
         if self.h:
             lib().ref_r1cs_free(self.h); self.h = None

@@ -529,6 +529,36 @@ void *ref_groth16_generate(void *pcs, const uint64_t *toxic /* 5*4 */) {
     free(u); free(At); free(Bt); free(Ct); free(sc);
     return kp;
 }
+
+/* The generator's exponents, canonical Fr, for building a key with an external batch exponentiation
+ * (the GPU fixed-base kernel): A_sc, B_sc [num_vars+1]; H_sc [m-1]; L_sc [num_vars-num_inputs]; ABC_sc [num_inputs+1]. */
+void ref_groth16_key_scalars(void *pcs, const uint64_t *toxic, uint64_t *A_sc, uint64_t *B_sc, uint64_t *H_sc, uint64_t *L_sc, uint64_t *ABC_sc) {
+    r1cs_t *cs = (r1cs_t *)pcs;
+    unsigned lm = domain_log(cs); size_t m = (size_t)1 << lm; size_t nv = cs->num_vars, ni = cs->num_inputs;
+    fr_t t, alpha, beta, gamma, delta;
+    fr_from_canon(&t, toxic); fr_from_canon(&alpha, toxic + 4); fr_from_canon(&beta, toxic + 8);
+    fr_from_canon(&gamma, toxic + 12); fr_from_canon(&delta, toxic + 16);
+    fr_t *u = (fr_t *)malloc(m * sizeof *u); dom_lagrange(u, lm, &t);
+    fr_t *At = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Bt = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Ct = (fr_t *)calloc(nv + 1, sizeof(fr_t));
+    for (size_t i = 0; i <= ni; i++) At[i] = u[cs->num_constraints + i];
+    fr_t *Xt[3] = {At, Bt, Ct};
+    for (int mm = 0; mm < 3; mm++)
+        for (size_t i = 0; i < cs->num_constraints; i++)
+            for (uint32_t e = cs->rp[mm][i]; e < cs->rp[mm][i + 1]; e++) {
+                fr_t x; fr_mul(&x, &u[i], &cs->co[mm][e]); fr_add(&Xt[mm][cs->ci[mm][e]], &Xt[mm][cs->ci[mm][e]], &x);
+            }
+    fr_t Zt = t; for (unsigned i = 0; i < lm; i++) fr_sqr(&Zt, &Zt); fr_sub(&Zt, &Zt, &FR_R);
+    fr_t gi, di; fr_inv(&gi, &gamma); fr_inv(&di, &delta);
+    for (size_t i = 0; i <= nv; i++) { fr_to_canon(A_sc + 4 * i, &At[i]); fr_to_canon(B_sc + 4 * i, &Bt[i]); }
+    { fr_t ti = FR_R, zd; fr_mul(&zd, &Zt, &di);
+      for (size_t i = 0; i + 1 < m; i++) { fr_t x; fr_mul(&x, &ti, &zd); fr_to_canon(H_sc + 4 * i, &x); fr_mul(&ti, &ti, &t); } }
+    for (size_t i = 0; i <= nv; i++) {
+        fr_t x, y; fr_mul(&x, &beta, &At[i]); fr_mul(&y, &alpha, &Bt[i]); fr_add(&x, &x, &y); fr_add(&x, &x, &Ct[i]);
+        if (i <= ni) { fr_mul(&x, &x, &gi); fr_to_canon(ABC_sc + 4 * i, &x); }
+        else { fr_mul(&x, &x, &di); fr_to_canon(L_sc + 4 * (i - ni - 1), &x); }
+    }
+    free(u); free(At); free(Bt); free(Ct);
+}
 void ref_keypair_free(void *p) { keypair_t *kp = (keypair_t *)p; free(kp->A_query); free(kp->B_query_g1); free(kp->B_query_g2); free(kp->H_query); free(kp->L_query); free(kp->gamma_ABC_g1); free(kp); }
 
 /* export a proving-key / verification-key component as canonical limbs.

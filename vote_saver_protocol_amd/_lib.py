@@ -38,6 +38,8 @@ PROTOTYPES = {
     "vsp_bases_free": (None, [_P, _P]),
     "vsp_msm_resident": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P]),
     "vsp_msm_resident_jacobian": (_I, [_P, _P, _SZ, _SZ, _P, _P]),
+    "vsp_msm_launch": (_I, [_P, _U, _P, _SZ, _SZ, _P]),
+    "vsp_msm_finish_jacobian": (_I, [_P, _U, _P]),
     "vsp_fold_jacobian": (_I, [_P, _I, _P, _SZ, _P, _P]),
     "vsp_ntt_fr": (_I, [_P, _P, _U, _I, _P]),
     "vsp_ntt_fr_device": (_I, [_P, _P, _U, _I, _P]),

@@ -149,6 +149,16 @@ class Bases:
         self.ctx.check(self.ctx.lib.vsp_msm_resident(self.ctx.h, self.h, first, n, _ptr(d_scalars), _ptr(out), C.byref(inf)))
         return out, bool(inf.value)
 
+    def msm_launch(self, slot, d_scalars, n=None, first=0):
+        """Enqueue the multi-exponentiation on work slot `slot` (own stream); pair with msm_finish_jacobian(slot)."""
+        n = self.n - first if n is None else n
+        self.ctx.check(self.ctx.lib.vsp_msm_launch(self.ctx.h, slot, self.h, first, n, _ptr(d_scalars)))
+
+    def msm_finish_jacobian(self, slot):
+        out = np.zeros(18 if self.group == 1 else 36, np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_msm_finish_jacobian(self.ctx.h, slot, _ptr(out)))
+        return out
+
     def msm_jacobian(self, d_scalars, n=None, first=0):
         """Same, result as the Jacobian partial-sum record (18 / 36 uint64) ranks exchange."""
         n = self.n - first if n is None else n

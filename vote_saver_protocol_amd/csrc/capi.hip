@@ -100,7 +100,8 @@ vsp_ctx *vsp_create(int device_ordinal) {
     ctx->device = device_ordinal;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     ctx->stream = ctx->own_stream;
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
     return ctx;
 }
 
@@ -109,12 +110,11 @@ void vsp_destroy(vsp_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch,
-                      &ctx->msm_cnt, &ctx->msm_off, &ctx->msm_cursor, &ctx->msm_nsub, &ctx->msm_suboff, &ctx->msm_blocksum, &ctx->msm_sorted,
-                      &ctx->msm_heavy, &ctx->msm_counters, &ctx->msm_digits, &ctx->msm_blockhist, &ctx->msm_partbucket, &ctx->msm_perm, &ctx->msm_sizehist, &ctx->msm_buckets, &ctx->msm_partials, &ctx->msm_dims, &ctx->msm_winres,
-                      &ctx->msm_scalars, &ctx->msm_tmp_bases, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
+                      &ctx->msm_scalars, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
                       &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
     for (DevBuf *b : bufs) free_buf(*b);
-    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    msm_free_slots(ctx);
+    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1); hipEventDestroy(ctx->ev_aux);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -225,6 +225,33 @@ int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first
         host_store_canon(out_jacobian, j.X); host_store_canon(out_jacobian + 6, j.Y); host_store_canon(out_jacobian + 12, j.Z);
     } else {
         Jacobian<HFp2> j = xyzz_to_jacobian(a2);
+        host_store_canon(out_jacobian, j.X.c0); host_store_canon(out_jacobian + 6, j.X.c1);
+        host_store_canon(out_jacobian + 12, j.Y.c0); host_store_canon(out_jacobian + 18, j.Y.c1);
+        host_store_canon(out_jacobian + 24, j.Z.c0); host_store_canon(out_jacobian + 30, j.Z.c1);
+    }
+    return VSP_OK;
+}
+
+// ---- pipelined form: up to VSP_MSM_SLOTS multi-exponentiations in flight, each on its own stream ----
+int vsp_msm_launch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!bases || (!d_scalars && n)) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
+    if (first > bases->n || n > bases->n - first) return set_error(ctx, VSP_ERR_ARG, "msm: range outside the resident bases");
+    VSP_HIP(hipSetDevice(ctx->device));
+    if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
+    if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, (const Fr *)d_scalars, n, -1);
+    return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, (const Fr *)d_scalars, n, -1);
+}
+int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (slot >= VSP_MSM_SLOTS || !out_jacobian) return set_error(ctx, VSP_ERR_ARG, "msm: bad slot or null output");
+    if (ctx->slot_group[slot] == 1) {
+        XYZZ<HFp> a; VSP_TRY(msm_g1_finish(ctx, slot, &a));
+        Jacobian<HFp> j = xyzz_to_jacobian(a);
+        host_store_canon(out_jacobian, j.X); host_store_canon(out_jacobian + 6, j.Y); host_store_canon(out_jacobian + 12, j.Z);
+    } else {
+        XYZZ<HFp2> a; VSP_TRY(msm_g2_finish(ctx, slot, &a));
+        Jacobian<HFp2> j = xyzz_to_jacobian(a);
         host_store_canon(out_jacobian, j.X.c0); host_store_canon(out_jacobian + 6, j.X.c1);
         host_store_canon(out_jacobian + 12, j.Y.c0); host_store_canon(out_jacobian + 18, j.Y.c1);
         host_store_canon(out_jacobian + 24, j.Z.c0); host_store_canon(out_jacobian + 30, j.Z.c1);

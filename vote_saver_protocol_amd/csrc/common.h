@@ -29,22 +29,47 @@ struct NttTables {
     bool pw_valid = false;
 };
 
+// digit-window geometry of one MSM
+struct MsmGeom {
+    unsigned c;         // window bits
+    unsigned W;         // windows
+    unsigned B;         // buckets per window = 2^(c-1)
+    unsigned q0, q1, q2;  // bucket index bit split, q0+q1+q2 = c-1
+    unsigned T;         // split threshold (max points per bucket part)
+    size_t n;
+    size_t G;           // W * B
+};
+
+// one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
+struct MsmWork {
+    static constexpr size_t PINNED_BYTES = 128 * 1024;
+    bool inited = false, own_stream = false, active = false, empty = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
+    DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
+    DevBuf buckets, partials, dims, winres;
+    void *h_pinned = nullptr;
+    MsmGeom g;
+    size_t n = 0, n_eff = 0;
+};
+static constexpr unsigned VSP_MSM_SLOTS = 6;
+
 }  // namespace vsp
 
 struct vsp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream in use
     hipStream_t own_stream = nullptr;   // created by vsp_create
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_aux = nullptr;
     std::string err;
     std::map<std::string, double> stats;
     std::map<std::string, long> opts;
     vsp::NttTables ntt;
     vsp::DevBuf ntt_scratch;
-    // MSM workspaces (grow only)
-    vsp::DevBuf msm_cnt, msm_off, msm_cursor, msm_nsub, msm_suboff, msm_blocksum, msm_sorted, msm_heavy, msm_counters;
-    vsp::DevBuf msm_digits, msm_blockhist, msm_partbucket, msm_perm, msm_sizehist;
-    vsp::DevBuf msm_buckets, msm_partials, msm_dims, msm_winres, msm_scalars, msm_tmp_bases;
+    // MSM work slots (slot 0 runs on the context's stream; the others own a stream each)
+    vsp::MsmWork msm_work[vsp::VSP_MSM_SLOTS];
+    int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
+    vsp::DevBuf msm_scalars;
     // fixed-base tables (generator multiples), built lazily
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
     // prover workspaces
@@ -96,6 +121,12 @@ int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr 
 // MSM on device-resident Montgomery bases; result as host XYZZ (Montgomery, 64-bit limbs)
 int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);
 int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp2> *out);
+int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot);
+int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
+int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot);
+int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
+int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
+void msm_free_slots(vsp_ctx *ctx);
 int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n);
 int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n);
 int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);

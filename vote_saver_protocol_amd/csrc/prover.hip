@@ -9,6 +9,8 @@
 //   A = alpha + sum z_i A_i + r delta          (G1)
 //   B = beta  + sum z_i B_i + s delta          (G2, and the same in G1 for C)
 //   C = sum h_i H_i + sum_{aux} z_i L_i + s A + r B_g1 - r s delta  (+ r_enc P1 in SAVER mode)
+#include <chrono>
+
 #include "common.h"
 
 namespace vsp {
@@ -200,6 +202,9 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
         return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
     VSP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *name) { double t = now(); ctx->stats[name] += t - t_prev; t_prev = t; };
     // z = (1, witness) canonical on device
     VSP_TRY(ensure(ctx, ctx->pr_z, (nv + 1) * sizeof(Fr)));
     VSP_TRY(ensure(ctx, ctx->pr_a, m * sizeof(Fr)));
@@ -210,6 +215,7 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     const uint64_t one4[4] = {1, 0, 0, 0};
     VSP_HIP(hipMemcpyAsync(dz, one4, 32, hipMemcpyHostToDevice, st));
     VSP_HIP(hipMemcpyAsync(dz + 1, witness, nv * 32, hipMemcpyHostToDevice, st));
+    VSP_HIP(hipEventRecord(ctx->ev_aux, st));          // z is resident
     // evaluation vectors (witness_map part 1): A z, B z, C z, plus the rows "input_i * 0 = 0" in A
     VSP_HIP(hipMemsetAsync(dA, 0, m * sizeof(Fr), st));
     VSP_HIP(hipMemsetAsync(dB, 0, m * sizeof(Fr), st));
@@ -221,27 +227,47 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
         VSP_LAUNCH_CHECK();
     }
     VSP_HIP(hipMemcpyAsync(dA + nc, dz, (ni + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
-    // the five multi-exponentiations
+    // The four multi-exponentiations over the witness do not depend on witness_map: they start now, each on its own
+    // stream (work slots 1-4); A_query, B_query(G1) and B_query(G2) share one digit sort / bucket plan (same scalars).
     XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
-    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->A->d, dz, nv + 1, &eA));
-    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->B1->d, dz, nv + 1, &eB1));
-    VSP_TRY(msm_g2_device(ctx, (const G2Affine *)pk->B2->d, dz, nv + 1, &eB2));
-    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->H->d, dH, m - 1, &eH));
-    VSP_TRY(msm_g1_device(ctx, (const G1Affine *)pk->L->d, dz + ni + 1, nv - ni, &eL));
-    // assembly on the host: a dozen group operations
+    {
+        hipStream_t s1, s2, s3, s4;
+        VSP_TRY(msm_slot_stream(ctx, 1, &s1)); VSP_TRY(msm_slot_stream(ctx, 2, &s2));
+        VSP_TRY(msm_slot_stream(ctx, 3, &s3)); VSP_TRY(msm_slot_stream(ctx, 4, &s4));
+        VSP_HIP(hipStreamWaitEvent(s1, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s2, ctx->ev_aux, 0));
+        VSP_HIP(hipStreamWaitEvent(s3, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s4, ctx->ev_aux, 0));
+    }
+    VSP_TRY(msm_g1_launch(ctx, 1, (const G1Affine *)pk->A->d, dz, nv + 1, -1));
+    VSP_TRY(msm_g2_launch(ctx, 3, (const G2Affine *)pk->B2->d, dz, nv + 1, 1));
+    VSP_TRY(msm_g1_launch(ctx, 2, (const G1Affine *)pk->B1->d, dz, nv + 1, 1));
+    VSP_TRY(msm_g1_launch(ctx, 4, (const G1Affine *)pk->L->d, dz + ni + 1, nv - ni, -1));
+    // witness_map (7 NTTs) and the H multi-exponentiation on the context's stream (slot 0)
+    VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+    VSP_TRY(msm_g1_launch(ctx, 0, (const G1Affine *)pk->H->d, dH, m - 1, -1));
+    lap("prove_launch_ms");
+    // host work that needs no MSM result, done while the GPU runs
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
-    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); { XYZZ<HFp> t = xyzz_mul_scalar(dj, r, 255); xyzz_add(gA, t); }
-    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); { XYZZ<HFp> t = xyzz_mul_scalar(dj, s, 255); xyzz_add(gB1, t); }
-    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); { XYZZ<HFp2> t = xyzz_mul_scalar(dj2, s, 255); xyzz_add(gB2, t); }
     HFr rr = host_load_canon<HFr>(r), ss = host_load_canon<HFr>(s);
     uint64_t rs4[4]; host_store_canon(rs4, mul(rr, ss));
+    XYZZ<HFp> r_delta = xyzz_mul_scalar(dj, r, 255), s_delta = xyzz_mul_scalar(dj, s, 255);
+    XYZZ<HFp> neg_rs_delta = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
+    XYZZ<HFp2> s_delta2 = xyzz_mul_scalar(dj2, s, 255);
+    XYZZ<HFp> saver = XYZZ<HFp>::inf();
+    if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
+    lap("prove_host_overlap_ms");
+    VSP_TRY(msm_g1_finish(ctx, 1, &eA)); VSP_TRY(msm_g1_finish(ctx, 2, &eB1)); VSP_TRY(msm_g1_finish(ctx, 4, &eL));
+    VSP_TRY(msm_g1_finish(ctx, 0, &eH)); VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
+    lap("prove_wait_ms");
+    // assembly: a handful of group operations
+    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
+    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
+    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2);
     XYZZ<HFp> gC = eH; xyzz_add(gC, eL);
     { XYZZ<HFp> t = xyzz_mul_scalar(gA, s, 255); xyzz_add(gC, t); }
     { XYZZ<HFp> t = xyzz_mul_scalar(gB1, r, 255); xyzz_add(gC, t); }
-    { XYZZ<HFp> t = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255)); xyzz_add(gC, t); }
-    if (saver_P1 && saver_r_enc) { XYZZ<HFp> t = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255); xyzz_add(gC, t); }
+    xyzz_add(gC, neg_rs_delta);
+    xyzz_add(gC, saver);
     Affine<HFp> a = xyzz_to_affine(gA), c = xyzz_to_affine(gC);
     Affine<HFp2> b = xyzz_to_affine(gB2);
     uint64_t A12[12], B24[24], C12[12];
@@ -250,6 +276,8 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     if (B_out) memcpy(B_out, B24, sizeof B24);
     if (C_out) memcpy(C_out, C12, sizeof C12);
     if (proof_out) { vsp_g1_compress(A12, proof_out); vsp_g2_compress(B24, proof_out + 48); vsp_g1_compress(C12, proof_out + 144); }
+    lap("prove_assembly_ms");
+    ctx->stats["prove_calls"] += 1;
     return VSP_OK;
 }
 
