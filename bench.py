@@ -278,6 +278,15 @@ def main():
     value = total_points / elapsed
     accum_avg_s = (accum_ms / accum_launches) * 1e-3 if accum_launches else float("nan")
     achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
+    # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
+    # from the committed summary of the same command, profiles/r1_c_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
+    traffic = None
+    try:
+        if args.log_n == 20:
+            with open(os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")) as f:
+                traffic = json.load(f)["k_accum_G1_2p20"]["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "G1 MSM points/sec at 2^20 (Groth16 prover hot path)",
         "value": value,
@@ -298,9 +307,11 @@ def main():
         "verified_bit_exact": verified,
         "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
+                     "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
-                     "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; see DESIGN.md"},
+                     "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
+                             "neighbouring step's kernels share the GPU (two-deep pipeline); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
+                             "profiles/r1_c_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
         "cpu_baseline": cpu_baseline,
     }
     if extras:
