@@ -53,6 +53,7 @@ struct MsmWork {
     size_t n = 0, n_eff = 0;
 };
 static constexpr unsigned VSP_MSM_SLOTS = 6;
+static constexpr int VSP_MSM_DENSE = -2;      // plan_from_slot value: the scalars are known to be dense, skip the 0/1 census
 
 }  // namespace vsp
 

@@ -243,7 +243,7 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     VSP_TRY(msm_g1_launch(ctx, 4, (const G1Affine *)pk->L->d, dz + ni + 1, nv - ni, -1));
     // witness_map (7 NTTs) and the H multi-exponentiation on the context's stream (slot 0)
     VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
-    VSP_TRY(msm_g1_launch(ctx, 0, (const G1Affine *)pk->H->d, dH, m - 1, -1));
+    VSP_TRY(msm_g1_launch(ctx, 0, (const G1Affine *)pk->H->d, dH, m - 1, VSP_MSM_DENSE));   // H coefficients are dense
     lap("prove_launch_ms");
     // host work that needs no MSM result, done while the GPU runs
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
