@@ -142,7 +142,8 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ                     # launched by torch.distributed.run (also with one rank: same code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -167,7 +168,7 @@ def main():
     all_dev = torch.zeros(18 * world, dtype=torch.int64, device=dev)
 
     def exchange(rec):
-        if world > 1:                                       # exchange step: 144-byte Jacobian record per rank
+        if use_dist:                                        # exchange step: 144-byte Jacobian record per rank
             rec_dev.copy_(torch.from_numpy(rec.view(np.int64)))
             dist.all_gather_into_tensor(all_dev, rec_dev)
             recs = all_dev.cpu().numpy().view(np.uint64).reshape(world, 18)
@@ -176,19 +177,20 @@ def main():
         return v.fold_jacobian(ctx, recs, 1)                # local fold + affine normalisation
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def run_steps(k_steps):
-        """k_steps full MSMs, software-pipelined two deep over work slots 0/1 (each on its own stream): the sort and
+        """k_steps full MSMs, software-pipelined two deep over work slots 1/2 (each on its own stream): the sort and
         bucket accumulation of step k+1 overlap the latency-bound bucket reduction and host Horner of step k."""
         res = None
-        bases.msm_launch(0, d_s)
+        sl = (1, 2)                                         # two work slots with streams of equal priority
+        bases.msm_launch(sl[0], d_s)
         for k in range(1, k_steps):
-            bases.msm_launch(k & 1, d_s)
-            res = exchange(bases.msm_finish_jacobian((k - 1) & 1))
-        return exchange(bases.msm_finish_jacobian((k_steps - 1) & 1))
+            bases.msm_launch(sl[k & 1], d_s)
+            res = exchange(bases.msm_finish_jacobian(sl[(k - 1) & 1]))
+        return exchange(bases.msm_finish_jacobian(sl[(k_steps - 1) & 1]))
 
     if args.warmup:
         result = run_steps(args.warmup)
@@ -201,7 +203,7 @@ def main():
     accum_ms = ctx.stat("msm_accum_ms")
     accum_launches = ctx.stat("msm_accum_launches")
     main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -209,7 +211,7 @@ def main():
     # ---- untimed verification: sum over all ranks of (sum_i k_i s_i) * G must equal the folded result
     e_local = int(sum((to_ints(ks) * to_ints(ss)).tolist()) % R_MOD)
     e_dev = torch.from_numpy(limbs(e_local, 4).view(np.int64)).to(dev)
-    if world > 1:
+    if use_dist:
         e_all = torch.zeros(4 * world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(e_all, e_dev)
         e_rows = e_all.cpu().numpy().view(np.uint64).reshape(world, 4)
@@ -320,7 +322,7 @@ def main():
         print(json.dumps(out))
     bases.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
