@@ -49,6 +49,9 @@ struct MsmWork {
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres;
     void *h_pinned = nullptr;
+    void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
+    hipEvent_t census_done = nullptr;
+    bool census_pending = false; size_t census_n = 0; const void *census_scalars = nullptr;
     MsmGeom g;
     size_t n = 0, n_eff = 0;
 };
@@ -70,6 +73,7 @@ struct vsp_ctx {
     // MSM work slots (slot 0 runs on the context's stream; the others own a stream each)
     vsp::MsmWork msm_work[vsp::VSP_MSM_SLOTS];
     int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
+    bool lds_attr_set[2] = {false, false};
     vsp::DevBuf msm_scalars;
     // fixed-base tables (generator multiples), built lazily
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
@@ -127,6 +131,7 @@ int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
 int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
+int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);
 int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n);
 int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n);

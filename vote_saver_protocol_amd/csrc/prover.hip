@@ -237,6 +237,11 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
         VSP_HIP(hipStreamWaitEvent(s1, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s2, ctx->ev_aux, 0));
         VSP_HIP(hipStreamWaitEvent(s3, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s4, ctx->ev_aux, 0));
     }
+    // both scalar-vector censuses are queued before any heavy kernel so that no launch below waits behind one
+    VSP_TRY(msm_slot_census(ctx, 1, dz, nv + 1));
+    VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
+    // (measured: giving the G2 chain its own plan and a higher stream priority is no faster -- the GPU is saturated
+    // for the whole proof, total work decides)
     VSP_TRY(msm_g1_launch(ctx, 1, (const G1Affine *)pk->A->d, dz, nv + 1, -1));
     VSP_TRY(msm_g2_launch(ctx, 3, (const G2Affine *)pk->B2->d, dz, nv + 1, 1));
     VSP_TRY(msm_g1_launch(ctx, 2, (const G1Affine *)pk->B1->d, dz, nv + 1, 1));
