@@ -50,7 +50,7 @@ def limbs(v, n):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
 
 
-def bench_prove(ctx, v, cref, o, dev, torch, log_m):
+def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     """BASELINE config 4: full r1cs_gg_ppzksnark prove on a synthetic satisfiable R1CS filling a 2^log_m domain
     (90 % boolean wires, 30 public inputs).  The proving key is built on the GPU (generator batch
     exponentiation), the proof is verified with the oracle's pairing, the CPU leg is the oracle's serial prover."""
@@ -70,6 +70,8 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m):
         d_pts = v.fixed_base_mul(ctx, d_sc, ks[name].shape[0], group)
         queries.append(ctx.bases_from_device(d_pts, ks[name].shape[0], group))
         ctx.dfree(d_pts)
+        if precompute:
+            queries[-1].precompute(0)
     G1l = np.array(o.g1_to_limbs(o.G1.gen), dtype=np.uint64); G2l = np.array(o.g2_to_limbs(o.G2.gen), dtype=np.uint64)
     alpha_g1 = cref.g1_mul(G1l, tox[1]); beta_g1 = cref.g1_mul(G1l, tox[2]); delta_g1 = cref.g1_mul(G1l, tox[4])
     beta_g2 = cref.g2_mul(G2l, tox[2]); delta_g2 = cref.g2_mul(G2l, tox[4]); gamma_g2 = cref.g2_mul(G2l, tox[3])
@@ -91,7 +93,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m):
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
     out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
-           f"prove_2p{log_m}_constraints": nc, f"prove_2p{log_m}_gpu_keygen_setup_s": setup_s,
+           f"prove_2p{log_m}_constraints": nc, f"prove_2p{log_m}_gpu_keygen_setup_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
            f"prove_2p{log_m}_phase_ms": phases}
     pk.free(); dcs.free(); [q.free() for q in queries]; cs.free()
     # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
@@ -103,6 +105,9 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m):
     eA, eB, eC = kp.prove(wit2, r, s_)
     cpu_dt = time.perf_counter() - t0
     q2 = [ctx.upload_bases(kp.part(nm), g) for nm, g in (("A_query", 1), ("B_query_g1", 1), ("B_query_g2", 2), ("H_query", 1), ("L_query", 1))]
+    if precompute:
+        for q in q2:
+            q.precompute(0)
     pk2 = v.ProvingKey(ctx, kp.part("alpha_g1")[0], kp.part("beta_g1")[0], kp.part("beta_g2")[0], kp.part("delta_g1")[0], kp.part("delta_g2")[0], *q2)
     A2, B2, C2 = cs2.export()
     dcs2 = v.R1CS(ctx, nc_s, ni, cs2.num_vars, A2, B2, C2)
@@ -125,6 +130,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary NTT / G2 measurements")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-pipeline", action="store_true", help="blocking MSM calls (one in flight): for clean per-kernel profiles")
+    ap.add_argument("--no-precompute", action="store_true", help="do not precompute the window multiples of the resident bases")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
     args = ap.parse_args()
@@ -163,6 +170,13 @@ def main():
     d_bases_canon = v.fixed_base_mul(ctx, d_k, n, 1)
     bases = ctx.bases_from_device(d_bases_canon, n, 1)
     del d_k
+    if not args.no_precompute:
+        # once per resident key: 2^(16 w) * P for the 16 windows (16x the bases' memory); every MSM then shares one bucket set
+        t_pre = time.perf_counter()
+        bases.precompute(16)
+        precompute_s = time.perf_counter() - t_pre
+    else:
+        precompute_s = None
 
     rec_dev = torch.zeros(18, dtype=torch.int64, device=dev)
     all_dev = torch.zeros(18 * world, dtype=torch.int64, device=dev)
@@ -184,6 +198,10 @@ def main():
     def run_steps(k_steps):
         """k_steps full MSMs, software-pipelined two deep over work slots 1/2 (each on its own stream): the sort and
         bucket accumulation of step k+1 overlap the latency-bound bucket reduction and host Horner of step k."""
+        if args.no_pipeline:
+            for _ in range(k_steps):
+                res = exchange(bases.msm_jacobian(d_s))
+            return res
         res = None
         sl = (1, 2)                                         # two work slots with streams of equal priority
         bases.msm_launch(sl[0], d_s)
@@ -273,7 +291,7 @@ def main():
             b2.free()
 
         if world == 1 and not args.no_prove:
-            extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n))
+            extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=not args.no_precompute))
 
     ctx.dfree(d_bases_canon)
     total_points = n * world * args.steps
@@ -305,7 +323,9 @@ def main():
         "config": {"workload": f"2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU, bases k_i*G, uniform scalars, "
                                f"resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
                                "RCCL all-gather of Jacobian partial sums + fold",
-                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w},
+                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w,
+                   "bases_precomputed_window_multiples": not args.no_precompute, "bases_memory_factor": 1 if args.no_precompute else main_w,
+                   "precompute_once_s": precompute_s},
         "verified_bit_exact": verified,
         "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -81,6 +81,11 @@ vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases /* host n x 2
 /* bases already in device memory (same canonical layout), e.g. produced by vsp_fixed_base_mul_* */
 vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n);
 vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n);
+/* Optional preprocessing of resident bases (once per proving key): store 2^(c*w) * P for every c-bit window w (c = window_bits,
+ * 0 = chosen from the number of bases: 16 from 2^19 bases up), 255/c + 1 slices = 16x the memory at c = 16.  Every multi-exponentiation over these bases then uses ONE shared set of
+ * 2^(c-1) buckets for all windows: the bucket reduction shrinks by the number of windows and the work per thread is uniform.
+ * Results are identical; sub-range calls (first, n) keep working. */
+int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits);
 size_t vsp_bases_count(const vsp_bases *b);
 void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b);
 

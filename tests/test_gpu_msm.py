@@ -192,3 +192,41 @@ def test_msm_pipelined_slots_and_shared_streams(ctx, cref):
         for d in (d_a, d_b, d_c):
             ctx.dfree(d)
         B1.free(); B2.free()
+
+
+@pytest.mark.parametrize("group,n", [(1, 3000), (2, 500)])
+@pytest.mark.parametrize("window_bits", [8, 13, 16])
+def test_msm_precomputed_window_multiples(ctx, cref, group, n, window_bits):
+    """vsp_bases_precompute: all windows share one bucket set; same results for random, boolean-heavy and all-equal
+    scalars, for sub-ranges, and for the pipelined form."""
+    ks = rand_fr_array(n, seed=50 + group)
+    bases = cref.g1_batch_mul_gen(ks) if group == 1 else cref.g2_batch_mul_gen(ks)
+    bases[5] = 0                                            # an infinity base
+    ref = cref.msm_g1 if group == 1 else cref.msm_g2
+    B = ctx.upload_bases(bases, group).precompute(window_bits)
+    B.precompute(window_bits)                               # idempotent
+    with pytest.raises(v.VspError):
+        B.precompute(9 if window_bits != 9 else 10)          # a different window size is refused
+    rng = np.random.default_rng(3)
+    cases = {"random": rand_fr_array(n, seed=60)}
+    sk = rand_fr_array(n, seed=61); m = rng.random(n) < 0.9; sk[m] = 0; sk[m, 0] = rng.integers(0, 2, size=int(m.sum()), dtype=np.uint64)
+    cases["boolean_90"] = sk
+    eq = np.zeros((n, 4), np.uint64); eq[:] = rand_fr_array(1, seed=62)[0]
+    cases["all_equal"] = eq
+    edge = rand_fr_array(n, seed=63); edge[0] = L(o.R - 1, 4); edge[1] = L(1, 4); edge[2] = 0
+    cases["edge"] = edge
+    try:
+        for name, ss in cases.items():
+            d_s = ctx.to_device(ss)
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, ref(bases, ss, mixed=True)), name
+            a, b = 17, n - 100
+            part, _ = B.msm(d_s + 32 * a, n=b - a, first=a)
+            assert np.array_equal(part, ref(bases[a:b], ss[a:b], mixed=True)), name
+            B.msm_launch(2, d_s); B.msm_launch(1, d_s + 32 * a, n=b - a, first=a)
+            r1 = B.msm_finish_jacobian(1); r2 = B.msm_finish_jacobian(2)
+            assert np.array_equal(v.fold_jacobian(ctx, r2[None], group), got) and np.array_equal(v.fold_jacobian(ctx, r1[None], group), part)
+            ctx.dfree(d_s)
+        assert ctx.stat("msm_bucket_sets") == 1 and ctx.stat("msm_window_bits") == window_bits
+    finally:
+        B.free()

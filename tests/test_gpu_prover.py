@@ -11,7 +11,7 @@ import vote_saver_protocol_amd as v
 pytestmark = pytest.mark.gpu
 
 
-def build(ctx, cref, nc, ni, seed):
+def build(ctx, cref, nc, ni, seed, precompute=False):
     gen = o.splitmix64(seed)
     cs, wit = cref.R1CS.synth(nc, ni, seed)
     tox = fr_array([o.rand_fr(gen) for _ in range(5)])
@@ -19,6 +19,10 @@ def build(ctx, cref, nc, ni, seed):
     A, B, Cm = cs.export()
     dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
     q = [ctx.upload_bases(kp.part(n), g) for n, g in (("A_query", 1), ("B_query_g1", 1), ("B_query_g2", 2), ("H_query", 1), ("L_query", 1))]
+    if precompute:
+        for i, x in enumerate(q):
+            if precompute == "all" or i in (0, 2, 3):       # "mixed": only some queries precomputed (no shared plan then)
+                x.precompute(16 if precompute == "all" else 12)
     pk = v.ProvingKey(ctx, kp.part("alpha_g1")[0], kp.part("beta_g1")[0], kp.part("beta_g2")[0], kp.part("delta_g1")[0], kp.part("delta_g2")[0], *q)
     r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
     return cs, wit, kp, dcs, pk, q, r, s
@@ -37,6 +41,15 @@ def test_prove_bit_exact_vs_oracle(ctx, cref, nc, ni):
     A2, B2, C2, _ = v.groth16_prove(ctx, dcs, pk, wit, r, s, saver_P1=P1, saver_r_enc=renc)
     sA, sB, sC = kp.prove(wit, r, s, P1=P1, r_enc=renc)
     assert np.array_equal(A2, sA) and np.array_equal(B2, sB) and np.array_equal(C2, sC)
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+@pytest.mark.parametrize("mode", ["all", "mixed"])
+def test_prove_with_precomputed_key_bit_exact(ctx, cref, mode):
+    cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, 700, 4, seed=11, precompute=mode)
+    A, B, Cc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s)
+    eA, eB, eC = kp.prove(wit, r, s)
+    assert np.array_equal(A, eA) and np.array_equal(B, eB) and np.array_equal(Cc, eC)
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
 
 

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "vsp_bases_upload_g2": (_P, [_P, _P, _SZ]),
     "vsp_bases_from_device_g1": (_P, [_P, _P, _SZ]),
     "vsp_bases_from_device_g2": (_P, [_P, _P, _SZ]),
+    "vsp_bases_precompute": (_I, [_P, _P, _U]),
     "vsp_bases_count": (_SZ, [_P]),
     "vsp_bases_free": (None, [_P, _P]),
     "vsp_msm_resident": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P]),

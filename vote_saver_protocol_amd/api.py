@@ -141,6 +141,11 @@ class Bases:
             self.ctx.lib.vsp_bases_free(self.ctx.h, self.h)
         self.h = None
 
+    def precompute(self, window_bits=0):
+        """Store the window multiples 2^(c*w) * P once (16x memory at c = 16); later multi-exponentiations share one bucket set."""
+        self.ctx.check(self.ctx.lib.vsp_bases_precompute(self.ctx.h, self.h, window_bits))
+        return self
+
     def msm(self, d_scalars, n=None, first=0):
         """sum_i scalars[i] * bases[first+i]; d_scalars is a device pointer / torch tensor.  -> (affine, is_inf)."""
         n = self.n - first if n is None else n

@@ -200,14 +200,57 @@ void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
 }
 
 // ---- MSM ----------------------------------------------------------------------------------------
+}  // extern "C"
+namespace vsp {
+// queue the multi-exponentiation over points [first, first+n) of resident bases on a work slot (plain or precomputed bases)
+int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot) {
+    if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
+    if (bases->pre_c) {
+        MsmPre pre{bases->n, first, bases->pre_c};
+        if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
+        return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
+    }
+    if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr);
+    return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr);
+}
+}  // namespace vsp
+extern "C" {
+
+int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!b) return set_error(ctx, VSP_ERR_ARG, "precompute: null bases");
+    if (window_bits == 0) {                     // automatic: about n * W / 2^(c-1) = 256 points per shared bucket
+        unsigned lg = ceil_log2(b->n ? b->n : 1);
+        window_bits = lg < 11 ? 8 : (lg - 3 > 16 ? 16 : lg - 3);
+    }
+    if (window_bits < 8 || window_bits > 16) return set_error(ctx, VSP_ERR_ARG, "precompute: window_bits must be 8..16");
+    if (b->pre_c == window_bits) return VSP_OK;
+    if (b->pre_c) return set_error(ctx, VSP_ERR_ARG, "precompute: bases already precomputed for another window size");
+    if (b->n == 0) { b->pre_c = window_bits; return VSP_OK; }
+    VSP_HIP(hipSetDevice(ctx->device));
+    const unsigned W = 255 / window_bits + 1;
+    const size_t esz = b->group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
+    if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_error(ctx, VSP_ERR_UNSUPPORTED, "precompute: table too large to index");
+    void *table = nullptr;
+    if (hipMalloc(&table, (size_t)W * b->n * esz) != hipSuccess) return set_error(ctx, VSP_ERR_NOMEM, "precompute: hipMalloc failed");
+    VSP_HIP(hipMemcpyAsync(table, b->d, b->n * esz, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = b->group == 1 ? msm_g1_precompute(ctx, (G1Affine *)table, b->n, window_bits) : msm_g2_precompute(ctx, (G2Affine *)table, b->n, window_bits);
+    if (rc != VSP_OK) { hipFree(table); return rc; }
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(b->d);
+    b->d = table; b->pre_c = window_bits;
+    return VSP_OK;
+}
+
 static int msm_resident_xyzz(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars,
                              XYZZ<HFp> *o1, XYZZ<HFp2> *o2) {
     if (!ctx) return VSP_ERR_ARG;
     if (!bases || (!d_scalars && n)) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
     if (first > bases->n || n > bases->n - first) return set_error(ctx, VSP_ERR_ARG, "msm: range outside the resident bases");
     VSP_HIP(hipSetDevice(ctx->device));
-    if (bases->group == 1) return msm_g1_device(ctx, (const G1Affine *)bases->d + first, (const Fr *)d_scalars, n, o1);
-    return msm_g2_device(ctx, (const G2Affine *)bases->d + first, (const Fr *)d_scalars, n, o2);
+    VSP_TRY(launch_on_bases(ctx, 0, bases, first, n, (const Fr *)d_scalars, -1));
+    if (bases->group == 1) return msm_g1_finish(ctx, 0, o1);
+    return msm_g2_finish(ctx, 0, o2);
 }
 
 int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, uint64_t *out_affine, int *out_is_inf) {
@@ -238,9 +281,7 @@ int vsp_msm_launch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t f
     if (!bases || (!d_scalars && n)) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
     if (first > bases->n || n > bases->n - first) return set_error(ctx, VSP_ERR_ARG, "msm: range outside the resident bases");
     VSP_HIP(hipSetDevice(ctx->device));
-    if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
-    if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, (const Fr *)d_scalars, n, -1);
-    return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, (const Fr *)d_scalars, n, -1);
+    return launch_on_bases(ctx, slot, bases, first, n, (const Fr *)d_scalars, -1);
 }
 int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian) {
     if (!ctx) return VSP_ERR_ARG;

@@ -37,8 +37,13 @@ struct MsmGeom {
     unsigned q0, q1, q2;  // bucket index bit split, q0+q1+q2 = c-1
     unsigned T;         // split threshold (max points per bucket part)
     size_t n;
-    size_t G;           // W * B
+    size_t G;           // Wr * B buckets in total
+    unsigned Wr;        // bucket sets: W (one per window) or 1 (precomputed window multiples, all windows share one set)
+    unsigned single;    // 1 in the shared-set mode
+    uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
 };
+// reference to the precomputed window multiples of resident bases
+struct MsmPre { size_t stride; size_t first; unsigned c; };
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
@@ -47,7 +52,7 @@ struct MsmWork {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
-    DevBuf buckets, partials, dims, winres;
+    DevBuf buckets, partials, dims, winres, medium;
     void *h_pinned = nullptr;
     void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
     hipEvent_t census_done = nullptr;
@@ -84,7 +89,9 @@ struct vsp_ctx {
 struct vsp_bases {
     int group = 1;          // 1 = G1, 2 = G2
     size_t n = 0;
-    void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form
+    void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
+                            // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
+    unsigned pre_c = 0;
 };
 
 struct vsp_r1cs {
@@ -126,10 +133,13 @@ int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr 
 // MSM on device-resident Montgomery bases; result as host XYZZ (Montgomery, 64-bit limbs)
 int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);
 int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp2> *out);
-int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot);
+int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
+int msm_g1_precompute(vsp_ctx *ctx, G1Affine *table, size_t n, unsigned c);
+int msm_g2_precompute(vsp_ctx *ctx, G2Affine *table, size_t n, unsigned c);
 int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
-int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot);
+int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
+int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
 int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);

@@ -242,13 +242,14 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
     // (measured: giving the G2 chain its own plan and a higher stream priority is no faster -- the GPU is saturated
     // for the whole proof, total work decides)
-    VSP_TRY(msm_g1_launch(ctx, 1, (const G1Affine *)pk->A->d, dz, nv + 1, -1));
-    VSP_TRY(msm_g2_launch(ctx, 3, (const G2Affine *)pk->B2->d, dz, nv + 1, 1));
-    VSP_TRY(msm_g1_launch(ctx, 2, (const G1Affine *)pk->B1->d, dz, nv + 1, 1));
-    VSP_TRY(msm_g1_launch(ctx, 4, (const G1Affine *)pk->L->d, dz + ni + 1, nv - ni, -1));
+    // (a plan can be shared only between bases that are precomputed alike)
+    VSP_TRY(launch_on_bases(ctx, 1, pk->A, 0, nv + 1, dz, -1));
+    VSP_TRY(launch_on_bases(ctx, 3, pk->B2, 0, nv + 1, dz, pk->B2->pre_c == pk->A->pre_c ? 1 : -1));
+    VSP_TRY(launch_on_bases(ctx, 2, pk->B1, 0, nv + 1, dz, pk->B1->pre_c == pk->A->pre_c ? 1 : -1));
+    VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, -1));
     // witness_map (7 NTTs) and the H multi-exponentiation on the context's stream (slot 0)
     VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
-    VSP_TRY(msm_g1_launch(ctx, 0, (const G1Affine *)pk->H->d, dH, m - 1, VSP_MSM_DENSE));   // H coefficients are dense
+    VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
     lap("prove_launch_ms");
     // host work that needs no MSM result, done while the GPU runs
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
