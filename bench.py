@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-pipeline", action="store_true", help="blocking MSM calls (one in flight): for clean per-kernel profiles")
     ap.add_argument("--no-precompute", action="store_true", help="do not precompute the window multiples of the resident bases")
+    ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
     args = ap.parse_args()
@@ -159,6 +160,8 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
+    if args.prove_h_first >= 0:
+        ctx.set_option("prove_h_first", args.prove_h_first)
 
     n = 1 << args.log_n
     # ---- synthetic inputs (SURVEY.md 8(d) cfg 2): bases k_i * G built on the GPU, uniform scalars; all resident

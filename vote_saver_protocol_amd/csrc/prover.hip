@@ -215,7 +215,6 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     const uint64_t one4[4] = {1, 0, 0, 0};
     VSP_HIP(hipMemcpyAsync(dz, one4, 32, hipMemcpyHostToDevice, st));
     VSP_HIP(hipMemcpyAsync(dz + 1, witness, nv * 32, hipMemcpyHostToDevice, st));
-    VSP_HIP(hipEventRecord(ctx->ev_aux, st));          // z is resident
     // evaluation vectors (witness_map part 1): A z, B z, C z, plus the rows "input_i * 0 = 0" in A
     VSP_HIP(hipMemsetAsync(dA, 0, m * sizeof(Fr), st));
     VSP_HIP(hipMemsetAsync(dB, 0, m * sizeof(Fr), st));
@@ -227,9 +226,20 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
         VSP_LAUNCH_CHECK();
     }
     VSP_HIP(hipMemcpyAsync(dA + nc, dz, (ni + 1) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    // The four multi-exponentiations over the witness do not depend on witness_map: they start now, each on its own
-    // stream (work slots 1-4); A_query, B_query(G1) and B_query(G2) share one digit sort / bucket plan (same scalars).
+    // Order of queueing: (1) the two scalar censuses, tiny, on the context's stream; (2) witness_map (7 NTTs) and the H
+    // multi-exponentiation, the longest dependent chain, on the context's stream; (3) the four multi-exponentiations over the
+    // witness -- independent of witness_map -- on the low-priority slots 1-4, filling the GPU around (2).  A_query, B_query(G1)
+    // and B_query(G2) share one digit sort / bucket plan (same scalars) when their bases are precomputed alike.
     XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
+    VSP_TRY(msm_slot_census(ctx, 1, dz, nv + 1));
+    VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
+    VSP_HIP(hipEventRecord(ctx->ev_aux, st));          // z resident and censuses queued
+    // option "prove_h_first" (default 1): queue witness_map + H before the witness multi-exponentiations, or after (0)
+    long h_first = 1; { auto it = ctx->opts.find("prove_h_first"); if (it != ctx->opts.end()) h_first = it->second; }
+    if (h_first) {
+        VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+        VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
+    }
     {
         hipStream_t s1, s2, s3, s4;
         VSP_TRY(msm_slot_stream(ctx, 1, &s1)); VSP_TRY(msm_slot_stream(ctx, 2, &s2));
@@ -237,19 +247,14 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
         VSP_HIP(hipStreamWaitEvent(s1, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s2, ctx->ev_aux, 0));
         VSP_HIP(hipStreamWaitEvent(s3, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s4, ctx->ev_aux, 0));
     }
-    // both scalar-vector censuses are queued before any heavy kernel so that no launch below waits behind one
-    VSP_TRY(msm_slot_census(ctx, 1, dz, nv + 1));
-    VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
-    // (measured: giving the G2 chain its own plan and a higher stream priority is no faster -- the GPU is saturated
-    // for the whole proof, total work decides)
-    // (a plan can be shared only between bases that are precomputed alike)
     VSP_TRY(launch_on_bases(ctx, 1, pk->A, 0, nv + 1, dz, -1));
     VSP_TRY(launch_on_bases(ctx, 3, pk->B2, 0, nv + 1, dz, pk->B2->pre_c == pk->A->pre_c ? 1 : -1));
     VSP_TRY(launch_on_bases(ctx, 2, pk->B1, 0, nv + 1, dz, pk->B1->pre_c == pk->A->pre_c ? 1 : -1));
     VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, -1));
-    // witness_map (7 NTTs) and the H multi-exponentiation on the context's stream (slot 0)
-    VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
-    VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
+    if (!h_first) {
+        VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+        VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));
+    }
     lap("prove_launch_ms");
     // host work that needs no MSM result, done while the GPU runs
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
