@@ -230,3 +230,45 @@ def test_msm_precomputed_window_multiples(ctx, cref, group, n, window_bits):
         assert ctx.stat("msm_bucket_sets") == 1 and ctx.stat("msm_window_bits") == window_bits
     finally:
         B.free()
+
+
+@pytest.mark.parametrize("precompute", [False, True])
+def test_msm_lds_sort_path_ragged_sizes(ctx, cref, precompute):
+    """n above the LDS-counting-sort threshold and not a power of two (ragged last chunk), dense and boolean-heavy scalars,
+    whole range and an unaligned sub-range, plain and precomputed bases -- all bit-exact vs the oracle's BDLO12."""
+    n = 50001
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=70))
+    B = ctx.upload_bases(bases, 1)
+    if precompute:
+        B.precompute(0)
+    rng = np.random.default_rng(8)
+    dense = rand_fr_array(n, seed=71)
+    sparse = rand_fr_array(n, seed=72); m = rng.random(n) < 0.9; sparse[m] = 0; sparse[m, 0] = rng.integers(0, 2, size=int(m.sum()), dtype=np.uint64)
+    try:
+        for name, ss in (("dense", dense), ("sparse", sparse)):
+            d_s = ctx.to_device(ss)
+            got, inf = B.msm(d_s)
+            assert not inf and np.array_equal(got, cref.msm_g1(bases, ss, mixed=True)), name
+            a, b = 333, 333 + 40000
+            part, _ = B.msm(d_s + 32 * a, n=b - a, first=a)
+            assert np.array_equal(part, cref.msm_g1(bases[a:b], ss[a:b], mixed=True)), name
+            ctx.dfree(d_s)
+    finally:
+        B.free()
+
+
+def test_msm_g2_lds_sort_path(ctx, cref):
+    """G2 at a size that takes the LDS counting sort (the benchmark's G2 sizes are otherwise unchecked)"""
+    n = 33000
+    bases = cref.g2_batch_mul_gen(rand_fr_array(n, seed=80))
+    ss = rand_fr_array(n, seed=81)
+    ss[:5000] = 0; ss[:5000, 0] = 1
+    exp = cref.msm_g2(bases, ss, mixed=True)
+    assert np.array_equal(v.multiexp(ctx, bases, ss, 2), exp)
+    B = ctx.upload_bases(bases, 2).precompute(0)
+    d_s = ctx.to_device(ss)
+    try:
+        got, _ = B.msm(d_s)
+        assert np.array_equal(got, exp)
+    finally:
+        ctx.dfree(d_s); B.free()
