@@ -193,12 +193,16 @@ template <class P> __device__ __forceinline__ Mont<P> mul_comba(const Mont<P> &a
 }
 #endif
 
+// host: one out-of-line copy per field (the host-side group formulas would otherwise inline dozens of 72-multiply bodies
+// each and take minutes to compile)
+template <class P> __attribute__((noinline)) Mont<P> mul_host(const Mont<P> &a, const Mont<P> &b) { return mul_cios<P>(a, b); }
+
 template <class P> VSP_HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (sizeof(typename P::limb_t) == 4) return mul_comba<P>(a, b);
     else return mul_cios<P>(a, b);          // 64-bit-limb (host) types are never run on the device
 #else
-    return mul_cios<P>(a, b);
+    return mul_host<P>(a, b);
 #endif
 }
 template <class P> VSP_HD Mont<P> sqr(const Mont<P> &a) { return mul(a, a); }

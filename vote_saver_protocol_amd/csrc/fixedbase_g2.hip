@@ -1,0 +1,3 @@
+// G2 instantiation of the generator-side batch exponentiation (see fixedbase_impl.inc)
+#define VSP_FB_GROUP 2
+#include "fixedbase_impl.inc"

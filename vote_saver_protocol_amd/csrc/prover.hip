@@ -28,110 +28,6 @@ __global__ __launch_bounds__(256) void k_fr_to_mont(Fr *a, size_t n) {
     if (i < n) a[i] = to_mont(a[i]);
 }
 
-// ---- fixed-base windowed multiplication: 32 windows of 8 bits, table[w][d-1] = d * 256^w * G (affine, Montgomery)
-static constexpr int FB_WINDOWS = 32, FB_ENTRIES = 255;
-
-template <class F>
-__global__ __launch_bounds__(256) void k_fixed_base(const Affine<F> *table, const Fr *scalars, size_t n, XYZZ<F> *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t *kb = (const uint8_t *)scalars[i].l;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = 0; w < FB_WINDOWS; w++) {
-        unsigned d = kb[w];
-        if (d) xyzz_madd(acc, table[w * FB_ENTRIES + d - 1]);
-    }
-    out[i] = acc;
-}
-
-// batch normalisation XYZZ -> canonical affine; each thread owns a chunk and does one inversion for it
-// (Montgomery's trick, prefix products kept in global scratch `pre`)
-static constexpr unsigned BA_CHUNK = 32;
-template <class F>
-__global__ __launch_bounds__(64) void k_batch_affine(const XYZZ<F> *in, size_t n, F *pre, Affine<F> *out) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t b = t * BA_CHUNK, e = b + BA_CHUNK < n ? b + BA_CHUNK : n;
-    if (b >= n) return;
-    F acc = F::one();
-    for (size_t i = b; i < e; i++) {
-        pre[i] = acc;
-        F z = in[i].ZZZ;
-        if (!is_zero(z)) acc = mul(acc, z);
-    }
-    F ai = inv(acc);
-    for (size_t i = e; i-- > b;) {
-        XYZZ<F> p = in[i];
-        Affine<F> r;
-        if (is_zero(p.ZZ)) { r.x = F::zero(); r.y = F::zero(); }
-        else {
-            F zi3 = mul(ai, pre[i]);          // 1 / ZZZ_i
-            ai = mul(ai, p.ZZZ);
-            F zi = mul(zi3, p.ZZ);            // 1 / Z
-            F zi2 = sqr(zi);
-            r.x = from_mont(mul(p.X, zi2));
-            r.y = from_mont(mul(p.Y, zi3));
-        }
-        out[i] = r;
-    }
-}
-
-template <class F, class HF>
-static int build_fixed_table(vsp_ctx *ctx, const Affine<HF> &gen, DevBuf &dst) {
-    if (dst.p) return VSP_OK;
-    std::vector<XYZZ<HF>> tj((size_t)FB_WINDOWS * FB_ENTRIES);
-    XYZZ<HF> wb = xyzz_from_affine(gen);
-    for (int w = 0; w < FB_WINDOWS; w++) {
-        XYZZ<HF> acc = wb;
-        for (int e = 0; e < FB_ENTRIES; e++) { tj[(size_t)w * FB_ENTRIES + e] = acc; xyzz_add(acc, wb); }
-        wb = acc;
-    }
-    // batch to affine on the host
-    size_t cnt = tj.size();
-    std::vector<HF> pre(cnt);
-    HF acc = HF::one();
-    for (size_t i = 0; i < cnt; i++) { pre[i] = acc; acc = mul(acc, tj[i].ZZZ); }
-    HF ai = inv(acc);
-    std::vector<Affine<HF>> ta(cnt);
-    for (size_t i = cnt; i-- > 0;) {
-        HF zi3 = mul(ai, pre[i]); ai = mul(ai, tj[i].ZZZ);
-        HF zi = mul(zi3, tj[i].ZZ), zi2 = sqr(zi);
-        ta[i].x = mul(tj[i].X, zi2); ta[i].y = mul(tj[i].Y, zi3);
-    }
-    VSP_TRY(ensure(ctx, dst, cnt * sizeof(Affine<F>)));
-    VSP_HIP(hipMemcpyAsync(dst.p, ta.data(), cnt * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream));
-    VSP_HIP(hipStreamSynchronize(ctx->stream));
-    return VSP_OK;
-}
-
-static const uint64_t G1_GEN[12] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL,
-                                    0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};
-static const uint64_t G2_GEN[24] = {0xd48056c8c121bdb8ULL, 0x0bac0326a805bbefULL, 0xb4510b647ae3d177ULL, 0xc6e47ad4fa403b02ULL, 0x260805272dc51051ULL, 0x024aa2b2f08f0a91ULL,
-                                    0xe5ac7d055d042b7eULL, 0x334cf11213945d57ULL, 0xb5da61bbdc7f5049ULL, 0x596bd0d09920b61aULL, 0x7dacd3a088274f65ULL, 0x13e02b6052719f60ULL,
-                                    0xe193548608b82801ULL, 0x923ac9cc3baca289ULL, 0x6d429a695160d12cULL, 0xadfd9baa8cbdd3a7ULL, 0x8cc9cdc6da2e351aULL, 0x0ce5d527727d6e11ULL,
-                                    0xaaa9075ff05f79beULL, 0x3f370d275cec1da1ULL, 0x267492ab572e99abULL, 0xcb3e287e85a763afULL, 0x32acd2b02bc28b99ULL, 0x0606c4a02ea734ccULL};
-
-template <class F, class HF>
-static int fixed_base_mul(vsp_ctx *ctx, const Affine<HF> &gen, DevBuf &table, const Fr *d_scalars, size_t n, void *d_out) {
-    if (!n) return VSP_OK;
-    VSP_TRY((build_fixed_table<F, HF>(ctx, gen, table)));
-    VSP_TRY(ensure(ctx, ctx->fb_tmp, n * sizeof(XYZZ<F>)));
-    VSP_TRY(ensure(ctx, ctx->fb_pre, n * sizeof(F)));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fixed_base<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const Affine<F> *)table.p, d_scalars, n, (XYZZ<F> *)ctx->fb_tmp.p);
-    VSP_LAUNCH_CHECK();
-    size_t chunks = (n + BA_CHUNK - 1) / BA_CHUNK;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_batch_affine<F>), dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, ctx->stream,
-                       (const XYZZ<F> *)ctx->fb_tmp.p, n, (F *)ctx->fb_pre.p, (Affine<F> *)d_out);
-    VSP_LAUNCH_CHECK();
-    return VSP_OK;
-}
-int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out) {
-    return fixed_base_mul<Fp, HFp>(ctx, host_load_g1(G1_GEN), ctx->fb_g1, d_scalars, n, d_out);
-}
-int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out) {
-    return fixed_base_mul<Fp2, HFp2>(ctx, host_load_g2(G2_GEN), ctx->fb_g2, d_scalars, n, d_out);
-}
-
 }  // namespace vsp
 
 using namespace vsp;
