@@ -61,24 +61,14 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     cs, wit = cref.R1CS.synth(nc, ni, 4)
     tox_i = [o.rand_fr(gen) for _ in range(5)]
     tox = np.array([o.int_to_limbs(x, 4) for x in tox_i], dtype=np.uint64)
-    t0 = time.perf_counter()
-    ks = cs.key_scalars(tox)
-    queries = []
-    for name, group in (("A", 1), ("B", 1), ("B", 2), ("H", 1), ("L", 1)):
-        d_sc = torch.from_numpy(ks[name].view(np.int64)).to(dev)
-        torch.cuda.synchronize()
-        d_pts = v.fixed_base_mul(ctx, d_sc, ks[name].shape[0], group)
-        queries.append(ctx.bases_from_device(d_pts, ks[name].shape[0], group))
-        ctx.dfree(d_pts)
-        if precompute:
-            queries[-1].precompute(0)
-    G1l = np.array(o.g1_to_limbs(o.G1.gen), dtype=np.uint64); G2l = np.array(o.g2_to_limbs(o.G2.gen), dtype=np.uint64)
-    alpha_g1 = cref.g1_mul(G1l, tox[1]); beta_g1 = cref.g1_mul(G1l, tox[2]); delta_g1 = cref.g1_mul(G1l, tox[4])
-    beta_g2 = cref.g2_mul(G2l, tox[2]); delta_g2 = cref.g2_mul(G2l, tox[4]); gamma_g2 = cref.g2_mul(G2l, tox[3])
-    pk = v.ProvingKey(ctx, alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, *queries)
     A, B, Cm = cs.export()
     dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
+    t0 = time.perf_counter()
+    kp = v.Keypair(ctx, dcs, tox, precompute=precompute)         # zk::generate on the GPU (incl. window-multiple precompute)
     setup_s = time.perf_counter() - t0
+    pk = kp.pk
+    alpha_g1, beta_g2, gamma_g2, delta_g2 = (kp.part(nm)[0] for nm in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2"))
+    gamma_abc = kp.part("gamma_ABC_g1")
     r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
     pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)          # warm-up (twiddles, workspaces)
     reps = 5
@@ -89,13 +79,13 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     dt = (time.perf_counter() - t0) / reps
     phases = {k: ctx.stat("prove_" + k + "_ms") / reps for k in ("launch", "host_overlap", "wait", "assembly")}
     vk = dict(alpha_g1=o.g1_from_limbs(alpha_g1), beta_g2=o.g2_from_limbs(beta_g2), gamma_g2=o.g2_from_limbs(gamma_g2),
-              delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in cref.g1_batch_mul_gen(ks["ABC"])])
+              delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in gamma_abc])
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
     out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
-           f"prove_2p{log_m}_constraints": nc, f"prove_2p{log_m}_gpu_keygen_setup_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
+           f"prove_2p{log_m}_constraints": nc, f"generate_2p{log_m}_gpu_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
            f"prove_2p{log_m}_phase_ms": phases}
-    pk.free(); dcs.free(); [q.free() for q in queries]; cs.free()
+    kp.free(); dcs.free(); cs.free()
     # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
     lg_s = 14
     nc_s = (1 << lg_s) - ni - 2

@@ -153,6 +153,20 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
                       const uint64_t *saver_P1 /* 12 or NULL */, const uint64_t *saver_r_enc /* 4 or NULL */,
                       uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
 
+/* ---- Groth16 generator: zk::generate<proof_system>(constraint_system), bin/cli/.../common.hpp:916-917 ----
+ * r1cs_gg_ppzksnark_generator with explicit toxic waste toxic[20] = (t, alpha, beta, gamma, delta), 4 limbs each, canonical
+ * (upstream draws them from algebraic_random_device).  Builds the whole key on the GPU: Lagrange coefficients at t, the
+ * per-variable QAP evaluations, the exponent vectors and the six batch exponentiations.  precompute != 0 additionally stores
+ * the window multiples of the five proving-key queries (vsp_bases_precompute).  The key owns its queries. */
+typedef struct vsp_keypair vsp_keypair;
+vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64_t toxic[20], int precompute);
+const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp);
+/* Key components as canonical affine points (host).  which: 0 A_query, 1 B_query (G1 half), 2 B_query (G2 half), 3 H_query,
+ * 4 L_query, 5 gamma_ABC_g1 (verification key), 6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2, 10 delta_g2, 11 gamma_g2. */
+size_t vsp_keypair_count(const vsp_keypair *kp, int which);
+int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t *out);
+void vsp_keypair_free(vsp_ctx *ctx, vsp_keypair *kp);
+
 /* ---- generator-side batch exponentiation (section 8(f).1; also builds synthetic benchmark bases) ---
  * out[i] = scalars[i] * generator, written to DEVICE memory as canonical affine points. */
 int vsp_fixed_base_mul_g1(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out /* n x 12 u64 */);

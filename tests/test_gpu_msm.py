@@ -272,3 +272,20 @@ def test_msm_g2_lds_sort_path(ctx, cref):
         assert np.array_equal(got, exp)
     finally:
         ctx.dfree(d_s); B.free()
+
+
+def test_msm_g2_sharded_jacobian_fold(ctx, cref):
+    """the sharded MSM's exchange record for G2 (288-byte Jacobian) and its fold (BASELINE config 5 shards G2 as well)"""
+    n = 1200
+    bases = cref.g2_batch_mul_gen(rand_fr_array(n, seed=90))
+    ss = rand_fr_array(n, seed=91)
+    B = ctx.upload_bases(bases, 2)
+    d_s = ctx.to_device(ss)
+    try:
+        cuts = [0, 400, 401, n]
+        recs = [B.msm_jacobian(d_s + 32 * a, n=b - a, first=a) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert recs[0].shape == (36,)
+        assert np.array_equal(v.fold_jacobian(ctx, np.stack(recs), 2), cref.msm_g2(bases, ss))
+        assert not v.fold_jacobian(ctx, np.zeros((0, 36), np.uint64), 2).any()          # empty fold = infinity
+    finally:
+        ctx.dfree(d_s); B.free()

@@ -51,6 +51,11 @@ PROTOTYPES = {
     "vsp_pk_create": (_P, [_P] * 11),
     "vsp_pk_free": (None, [_P, _P]),
     "vsp_groth16_prove": (_I, [_P] * 12),
+    "vsp_groth16_generate": (_P, [_P, _P, _P, _I]),
+    "vsp_keypair_pk": (_P, [_P]),
+    "vsp_keypair_count": (_SZ, [_P, _I]),
+    "vsp_keypair_export": (_I, [_P, _P, _I, _P]),
+    "vsp_keypair_free": (None, [_P, _P]),
     "vsp_fixed_base_mul_g1": (_I, [_P, _P, _SZ, _P]),
     "vsp_fixed_base_mul_g2": (_I, [_P, _P, _SZ, _P]),
     "vsp_selftest_field": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),

@@ -299,6 +299,40 @@ class ProvingKey:
         self.h = None
 
 
+KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "H_query": (3, 12), "L_query": (4, 12),
+             "gamma_ABC_g1": (5, 12), "alpha_g1": (6, 12), "beta_g1": (7, 12), "delta_g1": (8, 12), "beta_g2": (9, 24),
+             "delta_g2": (10, 24), "gamma_g2": (11, 24)}
+
+
+class Keypair:
+    """zk::generate<proof_system>(constraint_system) on the GPU with explicit toxic waste [5,4] = (t, alpha, beta, gamma, delta)."""
+
+    def __init__(self, ctx, cs, toxic, precompute=False):
+        self.ctx = ctx
+        toxic = _u64(toxic).reshape(20)
+        self.h = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(bool(precompute)))
+        if not self.h:
+            raise VspError("groth16_generate failed: " + ctx.last_error())
+        self.pk = _BorrowedPk(ctx.lib.vsp_keypair_pk(self.h))
+
+    def part(self, name):
+        which, width = KEY_PARTS[name]
+        n = self.ctx.lib.vsp_keypair_count(self.h, which)
+        out = np.zeros((n, width), np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_keypair_export(self.ctx.h, self.h, which, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_keypair_free(self.ctx.h, self.h)
+        self.h = None
+
+
+class _BorrowedPk:
+    def __init__(self, handle):
+        self.h = handle
+
+
 def groth16_prove(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
     """r1cs_gg_ppzksnark_prover::process with explicit r, s.  -> (A[12], B[24], C[12], proof_bytes[192])."""
     witness = _u64(witness, 4)

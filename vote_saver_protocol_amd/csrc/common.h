@@ -100,6 +100,16 @@ struct vsp_r1cs {
     uint32_t *rp[3] = {nullptr, nullptr, nullptr};
     uint32_t *ci[3] = {nullptr, nullptr, nullptr};
     void *co[3] = {nullptr, nullptr, nullptr};      // Fr Montgomery
+    // column-major copy (for the generator's per-variable accumulation): col_ptr [num_vars+2], row index, coefficient
+    uint32_t *cp[3] = {nullptr, nullptr, nullptr};
+    uint32_t *ri[3] = {nullptr, nullptr, nullptr};
+    void *cot[3] = {nullptr, nullptr, nullptr};     // Fr Montgomery
+};
+
+struct vsp_keypair {
+    vsp_pk *pk = nullptr;
+    vsp_bases *q[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // A, B_g1, B_g2, H, L, gamma_ABC_g1
+    uint64_t alpha_g1[12], beta_g1[12], delta_g1[12], beta_g2[24], delta_g2[24], gamma_g2[24];
 };
 
 struct vsp_pk {
@@ -147,6 +157,8 @@ int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t 
 int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n);
 int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
 int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
+int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi);
+HFr host_omega(unsigned log_m);
 
 // canonical <-> host Montgomery helpers
 template <class F> inline F host_load_canon(const uint64_t *p) { F t; memcpy(&t, p, sizeof(F)); return to_mont(t); }

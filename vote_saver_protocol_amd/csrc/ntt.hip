@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_ab_minus_c(Fr *h, const Fr *a, const Fr
 // ---- host side ----------------------------------------------------------------------------------
 static const uint64_t FR_ROOT_2_32[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL};
 
-static HFr host_omega(unsigned log_m) {
+HFr host_omega(unsigned log_m) {
     HFr w = host_load_canon<HFr>(FR_ROOT_2_32);
     for (unsigned i = log_m; i < 32; i++) w = sqr(w);
     return w;
@@ -152,7 +152,7 @@ static HFr host_from_u64(uint64_t v) { uint64_t c[4] = {v, 0, 0, 0}; return host
 static Fr to_dev(const HFr &h) { Fr d; memcpy(&d, &h, sizeof(Fr)); return d; }
 
 // lo[k] = base^k (k < 2^PW_LOG), hi[k] = base^(k << PW_LOG) (k < hi_count), Montgomery form
-static int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi) {
+int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi) {
     const size_t L = (size_t)1 << PW_LOG;
     std::vector<HFr> a(L), b(hi_count);
     HFr acc = HFr::one();

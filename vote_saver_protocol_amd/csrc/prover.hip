@@ -58,6 +58,24 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
         hipMemcpyAsync(cs->ci[m], ci[m], nnz * 4, hipMemcpyHostToDevice, ctx->stream);
         hipMemcpyAsync(cs->co[m], co[m], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
         if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)cs->co[m], nnz);
+        // column-major copy by a counting sort over the column index
+        std::vector<uint32_t> colptr(num_vars + 2, 0), rows(nnz ? nnz : 1);
+        std::vector<uint64_t> cot((nnz ? nnz : 1) * 4);
+        for (size_t e = 0; e < nnz; e++) colptr[ci[m][e] + 1]++;
+        for (size_t c = 0; c <= num_vars; c++) colptr[c + 1] += colptr[c];
+        std::vector<uint32_t> cur(colptr.begin(), colptr.end() - 1);
+        for (size_t r = 0; r < num_constraints; r++)
+            for (uint32_t e = rp[m][r]; e < rp[m][r + 1]; e++) {
+                uint32_t pos = cur[ci[m][e]]++;
+                rows[pos] = (uint32_t)r; memcpy(&cot[4 * (size_t)pos], co[m] + 4 * (size_t)e, 32);
+            }
+        ok = hipMalloc((void **)&cs->cp[m], (num_vars + 2) * 4) == hipSuccess && hipMalloc((void **)&cs->ri[m], (nnz ? nnz : 1) * 4) == hipSuccess &&
+             hipMalloc(&cs->cot[m], (nnz ? nnz : 1) * sizeof(Fr)) == hipSuccess;
+        if (!ok) { set_error(ctx, VSP_ERR_NOMEM, "r1cs_upload: hipMalloc"); vsp_r1cs_free(ctx, cs); return nullptr; }
+        hipMemcpy(cs->cp[m], colptr.data(), (num_vars + 2) * 4, hipMemcpyHostToDevice);
+        hipMemcpy(cs->ri[m], rows.data(), nnz * 4, hipMemcpyHostToDevice);
+        hipMemcpy(cs->cot[m], cot.data(), nnz * sizeof(Fr), hipMemcpyHostToDevice);
+        if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)cs->cot[m], nnz);
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error(ctx, VSP_ERR_HIP, "r1cs_upload: sync"); vsp_r1cs_free(ctx, cs); return nullptr; }
     return cs;
@@ -66,7 +84,10 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
 void vsp_r1cs_free(vsp_ctx *ctx, vsp_r1cs *cs) {
     if (!cs) return;
     if (ctx) hipSetDevice(ctx->device);
-    for (int m = 0; m < 3; m++) { if (cs->rp[m]) hipFree(cs->rp[m]); if (cs->ci[m]) hipFree(cs->ci[m]); if (cs->co[m]) hipFree(cs->co[m]); }
+    for (int m = 0; m < 3; m++) {
+        if (cs->rp[m]) hipFree(cs->rp[m]); if (cs->ci[m]) hipFree(cs->ci[m]); if (cs->co[m]) hipFree(cs->co[m]);
+        if (cs->cp[m]) hipFree(cs->cp[m]); if (cs->ri[m]) hipFree(cs->ri[m]); if (cs->cot[m]) hipFree(cs->cot[m]);
+    }
     delete cs;
 }
 
