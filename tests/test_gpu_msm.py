@@ -289,3 +289,42 @@ def test_msm_g2_sharded_jacobian_fold(ctx, cref):
         assert not v.fold_jacobian(ctx, np.zeros((0, 36), np.uint64), 2).any()          # empty fold = infinity
     finally:
         ctx.dfree(d_s); B.free()
+
+
+def test_msm_randomized_configurations(ctx, cref):
+    """30 seeded random configurations across the code paths: size (global-atomic and LDS sort paths, ragged), scalar
+    distribution, forced window size, plain / precomputed bases, whole range / sub-range -- each bit-exact vs the oracle."""
+    rng = np.random.default_rng(20260101)
+    nmax = 70000
+    all_bases = cref.g1_batch_mul_gen(rand_fr_array(nmax, seed=123))
+    for case in range(30):
+        n = int(rng.choice([1, 2, 63, 64, 65, 1000, 4095, 4096, 4097, 32767, 32768, 33001, int(rng.integers(2, nmax))]))
+        kind = rng.choice(["dense", "boolean", "small", "equal", "mostly_zero"])
+        ss = rand_fr_array(n, seed=1000 + case)
+        if kind == "boolean":
+            m = rng.random(n) < 0.85; ss[m] = 0; ss[m, 0] = rng.integers(0, 2, size=int(m.sum()), dtype=np.uint64)
+        elif kind == "small":
+            ss[:] = 0; ss[:, 0] = rng.integers(0, 70000, size=n, dtype=np.uint64)
+        elif kind == "equal":
+            ss[:] = ss[0]
+        elif kind == "mostly_zero":
+            m = rng.random(n) < 0.97; ss[m] = 0
+        pre = bool(rng.integers(0, 2))
+        first = int(rng.integers(0, nmax - n + 1))
+        bases = all_bases[first:first + n]
+        B = ctx.upload_bases(all_bases, 1)
+        forced = 0
+        try:
+            if pre:
+                B.precompute(int(rng.choice([0, 8, 11, 16])))
+            else:
+                forced = int(rng.choice([0, 0, 5, 9, 12, 16]))
+                ctx.set_option("msm_window_bits", forced)
+            d_s = ctx.to_device(ss)
+            got, _ = B.msm(d_s, n=n, first=first)
+            ctx.dfree(d_s)
+            exp = cref.msm_g1(bases, ss, mixed=True)
+            assert np.array_equal(got, exp), dict(case=case, n=n, kind=str(kind), pre=pre, first=first, forced=forced)
+        finally:
+            ctx.set_option("msm_window_bits", 0)
+            B.free()
