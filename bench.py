@@ -78,13 +78,35 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
         pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)
     dt = (time.perf_counter() - t0) / reps
     phases = {k: ctx.stat("prove_" + k + "_ms") / reps for k in ("launch", "host_overlap", "wait", "assembly")}
+    # throughput mode: contexts are independent and keys / constraint systems are plain device resources, so two host threads
+    # with a context each prove concurrently over ONE resident key (the tails of one proof overlap the bulk of the other)
+    import threading
+    ctx2 = v.Context(ctx.device)
+    per_thread = 6
+    outs = {}
+
+    def worker(c, tag):
+        v.groth16_prove(c, dcs, pk, wit, r, s_)
+        for _ in range(per_thread):
+            outs[tag] = v.groth16_prove(c, dcs, pk, wit, r, s_)
+
+    v.groth16_prove(ctx2, dcs, pk, wit, r, s_)             # warm the second context's workspaces
+    th = [threading.Thread(target=worker, args=(c, i)) for i, c in enumerate((ctx, ctx2))]
+    t0 = time.perf_counter()
+    for x in th: x.start()
+    for x in th: x.join()
+    dt2 = (time.perf_counter() - t0) / (2 * (per_thread + 1))
+    same = all(np.array_equal(outs[i][0], pa) and np.array_equal(outs[i][1], pb) and np.array_equal(outs[i][2], pc) for i in (0, 1))
+    ctx2.close()
     vk = dict(alpha_g1=o.g1_from_limbs(alpha_g1), beta_g2=o.g2_from_limbs(beta_g2), gamma_g2=o.g2_from_limbs(gamma_g2),
               delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in gamma_abc])
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
     out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
            f"prove_2p{log_m}_constraints": nc, f"generate_2p{log_m}_gpu_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
-           f"prove_2p{log_m}_phase_ms": phases}
+           f"prove_2p{log_m}_phase_ms": phases,
+           f"prove_2p{log_m}_two_contexts_ms_per_proof": dt2 * 1e3, f"prove_2p{log_m}_two_contexts_proofs_per_s": 1.0 / dt2,
+           f"prove_2p{log_m}_two_contexts_same_proof": bool(same)}
     kp.free(); dcs.free(); cs.free()
     # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
     lg_s = 14
@@ -297,6 +319,19 @@ def main():
             extras["g2_msm_2p18_points_per_s"] = n2 / dtg
             b2.free()
 
+        if world == 1 and not args.no_extras:
+            # host-buffer entry point (vsp_msm_g1): bases and scalars cross PCIe on every call -- never `value`
+            host_b = np.zeros((n, 12), np.uint64)
+            ctx.d2h(host_b, d_bases_canon)
+            v.multiexp(ctx, host_b, ss, 1)
+            th = time.perf_counter()
+            res_h = v.multiexp(ctx, host_b, ss, 1)
+            dth = time.perf_counter() - th
+            extras["msm_host_buffers_2p20_ms"] = dth * 1e3
+            extras["msm_host_buffers_2p20_points_per_s"] = n / dth
+            extras["msm_host_buffers_matches"] = bool(np.array_equal(res_h, result)) if world == 1 else None
+            del host_b
+
         if world == 1 and not args.no_prove:
             extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=not args.no_precompute))
 
@@ -355,7 +390,9 @@ def main():
         out["extras"] = extras
         if "prove_2p20_proofs_per_s" in extras:      # the other half of BASELINE.json's metric, same run
             out["secondary"] = {"metric": "Groth16 proofs/sec at 2^20 constraints (synthetic SAVER-shaped R1CS, pairing-verified)",
-                                "value": extras["prove_2p20_proofs_per_s"], "unit": "proofs/s", "ms_per_proof": extras["prove_2p20_ms"]}
+                                "value": extras.get("prove_2p20_two_contexts_proofs_per_s", extras["prove_2p20_proofs_per_s"]), "unit": "proofs/s",
+                                "mode": "two host threads / contexts proving concurrently over one resident key",
+                                "single_context_proofs_per_s": extras["prove_2p20_proofs_per_s"], "single_proof_latency_ms": extras["prove_2p20_ms"]}
     if rank == 0:
         print(json.dumps(out))
     bases.free()
