@@ -81,7 +81,8 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     # throughput mode: contexts are independent and keys / constraint systems are plain device resources, so two host threads
     # with a context each prove concurrently over ONE resident key (the tails of one proof overlap the bulk of the other)
     import threading
-    ctx2 = v.Context(ctx.device)
+    n_ctx = int(os.environ.get("VSP_BENCH_PROVE_CONTEXTS", "2"))
+    extra_ctx = [v.Context(ctx.device) for _ in range(n_ctx - 1)]
     per_thread = 6
     outs = {}
 
@@ -90,14 +91,16 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
         for _ in range(per_thread):
             outs[tag] = v.groth16_prove(c, dcs, pk, wit, r, s_)
 
-    v.groth16_prove(ctx2, dcs, pk, wit, r, s_)             # warm the second context's workspaces
-    th = [threading.Thread(target=worker, args=(c, i)) for i, c in enumerate((ctx, ctx2))]
+    for c in extra_ctx:
+        v.groth16_prove(c, dcs, pk, wit, r, s_)            # warm the other contexts' workspaces
+    th = [threading.Thread(target=worker, args=(c, i)) for i, c in enumerate([ctx] + extra_ctx)]
     t0 = time.perf_counter()
     for x in th: x.start()
     for x in th: x.join()
-    dt2 = (time.perf_counter() - t0) / (2 * (per_thread + 1))
-    same = all(np.array_equal(outs[i][0], pa) and np.array_equal(outs[i][1], pb) and np.array_equal(outs[i][2], pc) for i in (0, 1))
-    ctx2.close()
+    dt2 = (time.perf_counter() - t0) / (n_ctx * (per_thread + 1))
+    same = all(np.array_equal(outs[i][0], pa) and np.array_equal(outs[i][1], pb) and np.array_equal(outs[i][2], pc) for i in range(n_ctx))
+    for c in extra_ctx:
+        c.close()
     vk = dict(alpha_g1=o.g1_from_limbs(alpha_g1), beta_g2=o.g2_from_limbs(beta_g2), gamma_g2=o.g2_from_limbs(gamma_g2),
               delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in gamma_abc])
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
