@@ -28,7 +28,9 @@ def _load():
     lib.ref_r1cs_num_vars.restype = C.c_size_t
     lib.ref_r1cs_nnz.restype = C.c_size_t
     lib.ref_keypair_count.restype = C.c_size_t
-    lib.ref_r1cs_domain_log.restype = C.c_uint
+    lib.ref_r1cs_domain_size.restype = C.c_size_t
+    lib.ref_domain_size.restype = C.c_size_t
+    lib.ref_domain_op.restype = C.c_size_t
     return lib
 
 
@@ -117,6 +119,39 @@ def ntt_fr(a, inverse=False, coset=None):
     return a
 
 
+class Domain:
+    """make_evaluation_domain(min_size) of the C oracle: basic radix-2 or step radix-2 (libfqfft order)."""
+    OPS = {"fft": 0, "inverse_fft": 1, "coset_fft": 2, "inverse_coset_fft": 3, "lagrange": 4, "divide_by_z_on_coset": 5}
+
+    def __init__(self, min_size):
+        self.min_size = min_size
+        self.m = lib().ref_domain_size(C.c_size_t(min_size))
+        if self.m == 0:
+            raise ValueError("no radix-2 family domain for this size")
+        self.is_step = bool(lib().ref_domain_is_step(C.c_size_t(min_size)))
+
+    def _op(self, op, a, aux):
+        a = _u64(a).copy().reshape(-1, 4)
+        assert a.shape[0] == self.m
+        lib().ref_domain_op(C.c_size_t(self.min_size), C.c_int(self.OPS[op]), _p(a), _p(None if aux is None else _u64(aux)))
+        return a
+
+    def fft(self, a): return self._op("fft", a, None)
+    def inverse_fft(self, a): return self._op("inverse_fft", a, None)
+    def coset_fft(self, a, g): return self._op("coset_fft", a, g)
+    def inverse_coset_fft(self, a, g): return self._op("inverse_coset_fft", a, g)
+    def divide_by_z_on_coset(self, a, g): return self._op("divide_by_z_on_coset", a, g)
+
+    def evaluate_all_lagrange_polynomials(self, t):
+        return self._op("lagrange", np.zeros((self.m, 4), np.uint64), t)
+
+    def get_domain_element(self, idx):
+        out = np.zeros(4, np.uint64); lib().ref_domain_element(C.c_size_t(self.min_size), C.c_size_t(idx), _p(out)); return out
+
+    def compute_vanishing_polynomial(self, t):
+        out = np.zeros(4, np.uint64); lib().ref_domain_vanishing(C.c_size_t(self.min_size), _p(_u64(t)), _p(out)); return out
+
+
 class R1CS:
     """Handle on a C-side constraint system (CSR triples A, B, C)."""
 
@@ -124,7 +159,8 @@ class R1CS:
         self.h = C.c_void_p(handle)
         self.num_constraints, self.num_inputs = num_constraints, num_inputs
         self.num_vars = lib().ref_r1cs_num_vars(self.h)
-        self.log_m = lib().ref_r1cs_domain_log(self.h)
+        self.m = lib().ref_r1cs_domain_size(self.h)          # make_evaluation_domain(num_constraints + num_inputs + 1)
+        self.is_step = bool(lib().ref_r1cs_domain_is_step(self.h))
 
     @classmethod
     def synth(cls, num_constraints, num_inputs, seed):
@@ -150,7 +186,7 @@ class R1CS:
         return bool(lib().ref_r1cs_is_satisfied(self.h, _p(_u64(witness))))
 
     def witness_map(self, witness, want_abc=False):
-        m = 1 << self.log_m
+        m = self.m
         H = np.zeros((m, 4), np.uint64)
         if want_abc:
             Az, Bz, Cz = (np.zeros((m, 4), np.uint64) for _ in range(3))
@@ -161,7 +197,7 @@ class R1CS:
 
     def key_scalars(self, toxic):
         """The generator's exponents (canonical Fr) for (A_query, B_query, H_query, L_query, gamma_ABC)."""
-        m = 1 << self.log_m
+        m = self.m
         nv, ni = self.num_vars, self.num_inputs
         A = np.zeros((nv + 1, 4), np.uint64); B = np.zeros((nv + 1, 4), np.uint64)
         H = np.zeros((m - 1, 4), np.uint64); Lq = np.zeros((nv - ni, 4), np.uint64); ABC = np.zeros((ni + 1, 4), np.uint64)

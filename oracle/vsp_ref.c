@@ -275,14 +275,14 @@ static void fr_mul_by_coset(fr_t *a, size_t n, const fr_t *g) {
     fr_t u = *g;
     for (size_t i = 1; i < n; i++) { fr_mul(&a[i], &a[i], &u); fr_mul(&u, &u, g); }
 }
-static void dom_fft(fr_t *a, unsigned log_m) { fr_t w = fr_omega(log_m); fr_fft_serial(a, log_m, &w); }
-static void dom_ifft(fr_t *a, unsigned log_m) {
+static void r2_fft(fr_t *a, unsigned log_m) { fr_t w = fr_omega(log_m); fr_fft_serial(a, log_m, &w); }
+static void r2_ifft(fr_t *a, unsigned log_m) {
     fr_t w = fr_omega(log_m), wi; fr_inv(&wi, &w); fr_fft_serial(a, log_m, &wi);
     fr_t m = fr_from_u64((uint64_t)1 << log_m), mi; fr_inv(&mi, &m);
     for (size_t i = 0; i < ((size_t)1 << log_m); i++) fr_mul(&a[i], &a[i], &mi);
 }
-static void dom_coset_fft(fr_t *a, unsigned log_m, const fr_t *g) { fr_mul_by_coset(a, (size_t)1 << log_m, g); dom_fft(a, log_m); }
-static void dom_icoset_fft(fr_t *a, unsigned log_m, const fr_t *g) { dom_ifft(a, log_m); fr_t gi; fr_inv(&gi, g); fr_mul_by_coset(a, (size_t)1 << log_m, &gi); }
+static void r2_coset_fft(fr_t *a, unsigned log_m, const fr_t *g) { fr_mul_by_coset(a, (size_t)1 << log_m, g); r2_fft(a, log_m); }
+static void r2_icoset_fft(fr_t *a, unsigned log_m, const fr_t *g) { r2_ifft(a, log_m); fr_t gi; fr_inv(&gi, g); fr_mul_by_coset(a, (size_t)1 << log_m, &gi); }
 
 void ref_ntt_fr(uint64_t *a, unsigned log_m, int inverse, const uint64_t *coset_g) {
     ref_init();
@@ -290,14 +290,14 @@ void ref_ntt_fr(uint64_t *a, unsigned log_m, int inverse, const uint64_t *coset_
     fr_t *v = (fr_t *)malloc(n * sizeof *v);
     for (size_t i = 0; i < n; i++) fr_from_canon(&v[i], a + 4 * i);
     fr_t g; if (coset_g) fr_from_canon(&g, coset_g);
-    if (!inverse) { if (coset_g) dom_coset_fft(v, log_m, &g); else dom_fft(v, log_m); }
-    else { if (coset_g) dom_icoset_fft(v, log_m, &g); else dom_ifft(v, log_m); }
+    if (!inverse) { if (coset_g) r2_coset_fft(v, log_m, &g); else r2_fft(v, log_m); }
+    else { if (coset_g) r2_icoset_fft(v, log_m, &g); else r2_ifft(v, log_m); }
     for (size_t i = 0; i < n; i++) fr_to_canon(a + 4 * i, &v[i]);
     free(v);
 }
 
 /* evaluate_all_lagrange_polynomials(t) for the radix-2 domain */
-static void dom_lagrange(fr_t *u, unsigned log_m, const fr_t *t) {
+static void r2_lagrange(fr_t *u, unsigned log_m, const fr_t *t) {
     size_t m = (size_t)1 << log_m;
     fr_t tm = *t; for (unsigned i = 0; i < log_m; i++) fr_sqr(&tm, &tm);
     fr_t omega = fr_omega(log_m);
@@ -319,6 +319,149 @@ static void dom_lagrange(fr_t *u, unsigned log_m, const fr_t *t) {
     for (size_t i = 0; i < m; i++) { fr_mul(&u[i], &l, &den[i]); fr_mul(&l, &l, &omega); }
     free(den); free(pre);
 }
+
+/* ---- the domain make_evaluation_domain(min_size) selects (libfqfft get_evaluation_domain.tcc order: basic_radix2(min_size),
+ * extended_radix2, step_radix2(min_size), then the same three at big + rounded_small; for Fr (two-adicity 32) and sizes < 2^32
+ * the extended domain (m = 2^33) never constructs and one of the others always does) ---- */
+typedef struct { size_t m, big_m, small_m; unsigned log_big, log_small; int step; } dom_t;
+static unsigned clog2(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
+static int dom_try_basic(dom_t *d, size_t m) {
+    if (m <= 1 || m != ((size_t)1 << clog2(m)) || clog2(m) > 32) return 0;
+    d->m = d->big_m = m; d->small_m = 0; d->log_big = clog2(m); d->log_small = 0; d->step = 0; return 1;
+}
+static int dom_try_step(dom_t *d, size_t m) {
+    if (m <= 1 || clog2(m) > 32) return 0;
+    size_t big = (size_t)1 << (clog2(m) - 1), small = m - big;
+    if (small != ((size_t)1 << clog2(small))) return 0;
+    d->m = m; d->big_m = big; d->small_m = small; d->log_big = clog2(big); d->log_small = clog2(small); d->step = 1; return 1;
+}
+static int dom_make(dom_t *d, size_t min_size) {
+    if (min_size <= 1) return 0;
+    size_t big = (size_t)1 << (clog2(min_size) - 1), small = min_size - big, rounded = (size_t)1 << clog2(small);
+    return dom_try_basic(d, min_size) || dom_try_step(d, min_size) || dom_try_basic(d, big + rounded) || dom_try_step(d, big + rounded);
+}
+static fr_t fr_pow_u64(const fr_t *b, uint64_t e) { uint64_t ee[1] = {e}; fr_t r; fr_pow(&r, b, ee, 1); return r; }
+
+/* step_radix2_domain.tcc FFT / iFFT */
+static void step_fft(const dom_t *D, fr_t *a) {
+    size_t big = D->big_m, small = D->small_m;
+    fr_t omega = fr_omega(D->log_big + 1);
+    fr_t *c = (fr_t *)malloc(big * sizeof *c), *d = (fr_t *)malloc(big * sizeof *d), *e = (fr_t *)calloc(small, sizeof *e);
+    fr_t w = FR_R;
+    for (size_t i = 0; i < big; i++) {
+        if (i < small) { fr_add(&c[i], &a[i], &a[i + big]); fr_t t; fr_sub(&t, &a[i], &a[i + big]); fr_mul(&d[i], &w, &t); }
+        else { c[i] = a[i]; fr_mul(&d[i], &w, &a[i]); }
+        fr_mul(&w, &w, &omega);
+    }
+    size_t compr = big / small;
+    for (size_t i = 0; i < small; i++) for (size_t j = 0; j < compr; j++) fr_add(&e[i], &e[i], &d[i + j * small]);
+    if (big > 1) r2_fft(c, D->log_big);
+    if (small > 1) r2_fft(e, D->log_small);
+    memcpy(a, c, big * sizeof *c); memcpy(a + big, e, small * sizeof *e);
+    free(c); free(d); free(e);
+}
+static void step_ifft(const dom_t *D, fr_t *a) {
+    size_t big = D->big_m, small = D->small_m;
+    fr_t omega = fr_omega(D->log_big + 1);
+    fr_t *U0 = (fr_t *)malloc(big * sizeof *U0), *U1 = (fr_t *)malloc(small * sizeof *U1), *tmp = (fr_t *)malloc(big * sizeof *tmp);
+    memcpy(U0, a, big * sizeof *U0); memcpy(U1, a + big, small * sizeof *U1);
+    if (big > 1) r2_ifft(U0, D->log_big);
+    if (small > 1) r2_ifft(U1, D->log_small);
+    fr_t w = FR_R;
+    for (size_t i = 0; i < big; i++) { fr_mul(&tmp[i], &U0[i], &w); fr_mul(&w, &w, &omega); }
+    for (size_t i = small; i < big; i++) a[i] = U0[i];
+    size_t compr = big / small;
+    for (size_t i = 0; i < small; i++) for (size_t j = 1; j < compr; j++) fr_sub(&U1[i], &U1[i], &tmp[i + j * small]);
+    fr_t oi; fr_inv(&oi, &omega); w = FR_R;
+    for (size_t i = 0; i < small; i++) { fr_mul(&U1[i], &U1[i], &w); fr_mul(&w, &w, &oi); }
+    fr_t two = fr_from_u64(2), half; fr_inv(&half, &two);
+    for (size_t i = 0; i < small; i++) {
+        fr_t s, t; fr_add(&s, &U0[i], &U1[i]); fr_sub(&t, &U0[i], &U1[i]);
+        fr_mul(&a[i], &s, &half); fr_mul(&a[big + i], &t, &half);
+    }
+    free(U0); free(U1); free(tmp);
+}
+static void dom_fft(const dom_t *D, fr_t *a) { if (D->step) step_fft(D, a); else r2_fft(a, D->log_big); }
+static void dom_ifft(const dom_t *D, fr_t *a) { if (D->step) step_ifft(D, a); else r2_ifft(a, D->log_big); }
+static void dom_coset_fft(const dom_t *D, fr_t *a, const fr_t *g) { fr_mul_by_coset(a, D->m, g); dom_fft(D, a); }
+static void dom_icoset_fft(const dom_t *D, fr_t *a, const fr_t *g) { dom_ifft(D, a); fr_t gi; fr_inv(&gi, g); fr_mul_by_coset(a, D->m, &gi); }
+static fr_t dom_element(const dom_t *D, size_t idx) {
+    if (!D->step) { fr_t w = fr_omega(D->log_big); return fr_pow_u64(&w, idx); }
+    fr_t omega = fr_omega(D->log_big + 1);
+    if (idx < D->big_m) { fr_t bw; fr_sqr(&bw, &omega); return fr_pow_u64(&bw, idx); }
+    fr_t sw = fr_omega(D->log_small), r = fr_pow_u64(&sw, idx - D->big_m); fr_mul(&r, &r, &omega); return r;
+}
+static fr_t dom_vanishing(const dom_t *D, const fr_t *t) {
+    fr_t a = fr_pow_u64(t, D->big_m); fr_sub(&a, &a, &FR_R);
+    if (!D->step) return a;
+    fr_t omega = fr_omega(D->log_big + 1), b = fr_pow_u64(t, D->small_m), ws = fr_pow_u64(&omega, D->small_m);
+    fr_sub(&b, &b, &ws); fr_mul(&a, &a, &b); return a;
+}
+static void fr_batch_inv(fr_t *v, size_t n) {
+    fr_t *pre = (fr_t *)malloc((n ? n : 1) * sizeof *pre); fr_t acc = FR_R;
+    for (size_t i = 0; i < n; i++) { pre[i] = acc; fr_mul(&acc, &acc, &v[i]); }
+    fr_t inv; fr_inv(&inv, &acc);
+    for (size_t i = n; i-- > 0;) { fr_t di; fr_mul(&di, &inv, &pre[i]); fr_mul(&inv, &inv, &v[i]); v[i] = di; }
+    free(pre);
+}
+/* evaluate_all_lagrange_polynomials (step_radix2_domain.tcc; t outside the domain in the step case) */
+static void dom_lagrange(const dom_t *D, fr_t *u, const fr_t *t) {
+    if (!D->step) { r2_lagrange(u, D->log_big, t); return; }
+    size_t big = D->big_m, small = D->small_m;
+    fr_t omega = fr_omega(D->log_big + 1), oi; fr_inv(&oi, &omega);
+    fr_t ts; fr_mul(&ts, t, &oi);
+    if (big > 1) r2_lagrange(u, D->log_big, t); else u[0] = FR_R;
+    if (small > 1) r2_lagrange(u + big, D->log_small, &ts); else u[big] = FR_R;
+    fr_t ws = fr_pow_u64(&omega, small), L0 = fr_pow_u64(t, small); fr_sub(&L0, &L0, &ws);
+    fr_t bws; fr_sqr(&bws, &ws);                       /* big_omega^small_m */
+    fr_t *den = (fr_t *)malloc(big * sizeof *den); fr_t elt = FR_R;
+    for (size_t i = 0; i < big; i++) { fr_sub(&den[i], &elt, &ws); fr_mul(&elt, &elt, &bws); }
+    fr_batch_inv(den, big);
+    for (size_t i = 0; i < big; i++) { fr_mul(&u[i], &u[i], &L0); fr_mul(&u[i], &u[i], &den[i]); }
+    free(den);
+    fr_t L1 = fr_pow_u64(t, big), d1 = fr_pow_u64(&omega, big); fr_sub(&L1, &L1, &FR_R); fr_sub(&d1, &d1, &FR_R); fr_inv(&d1, &d1); fr_mul(&L1, &L1, &d1);
+    for (size_t i = 0; i < small; i++) fr_mul(&u[big + i], &u[big + i], &L1);
+}
+/* divide_by_Z_on_coset */
+static void dom_divide_by_z_on_coset(const dom_t *D, fr_t *P, const fr_t *g) {
+    if (!D->step) { fr_t zi = dom_vanishing(D, g); fr_inv(&zi, &zi); for (size_t i = 0; i < D->m; i++) fr_mul(&P[i], &P[i], &zi); return; }
+    size_t big = D->big_m, small = D->small_m;
+    fr_t omega = fr_omega(D->log_big + 1);
+    fr_t Z0 = fr_pow_u64(g, big); fr_sub(&Z0, &Z0, &FR_R);
+    fr_t cZ0 = fr_pow_u64(g, small); fr_mul(&cZ0, &cZ0, &Z0);
+    fr_t w1 = fr_pow_u64(&omega, small), w2; fr_sqr(&w2, &w1);
+    fr_t w1Z0; fr_mul(&w1Z0, &w1, &Z0);
+    fr_t *den = (fr_t *)malloc(big * sizeof *den); fr_t elt = FR_R;
+    for (size_t i = 0; i < big; i++) { fr_mul(&den[i], &cZ0, &elt); fr_sub(&den[i], &den[i], &w1Z0); fr_mul(&elt, &elt, &w2); }
+    fr_batch_inv(den, big);
+    for (size_t i = 0; i < big; i++) fr_mul(&P[i], &P[i], &den[i]);
+    free(den);
+    fr_t go; fr_mul(&go, g, &omega);
+    fr_t Z1 = dom_vanishing(D, &go); fr_inv(&Z1, &Z1);
+    for (size_t i = 0; i < small; i++) fr_mul(&P[big + i], &P[big + i], &Z1);
+}
+
+/* exported domain operations (canonical limbs): op 0 fft, 1 inverse fft, 2 coset fft, 3 inverse coset fft (g = aux),
+ * 4 lagrange at t = aux (a receives m values), 5 divide_by_z_on_coset with g = aux.  Returns m (0 = no such domain). */
+size_t ref_domain_size(size_t min_size) { dom_t D; return dom_make(&D, min_size) ? D.m : 0; }
+int ref_domain_is_step(size_t min_size) { dom_t D; return dom_make(&D, min_size) ? D.step : -1; }
+size_t ref_domain_op(size_t min_size, int op, uint64_t *a, const uint64_t *aux) {
+    ref_init();
+    dom_t D; if (!dom_make(&D, min_size)) return 0;
+    fr_t *v = (fr_t *)malloc(D.m * sizeof *v);
+    for (size_t i = 0; i < D.m; i++) fr_from_canon(&v[i], a + 4 * i);
+    fr_t x; if (aux) fr_from_canon(&x, aux);
+    switch (op) {
+        case 0: dom_fft(&D, v); break; case 1: dom_ifft(&D, v); break;
+        case 2: dom_coset_fft(&D, v, &x); break; case 3: dom_icoset_fft(&D, v, &x); break;
+        case 4: dom_lagrange(&D, v, &x); break; case 5: dom_divide_by_z_on_coset(&D, v, &x); break;
+    }
+    for (size_t i = 0; i < D.m; i++) fr_to_canon(a + 4 * i, &v[i]);
+    free(v);
+    return D.m;
+}
+void ref_domain_element(size_t min_size, size_t idx, uint64_t *out) { ref_init(); dom_t D; dom_make(&D, min_size); fr_t e = dom_element(&D, idx); fr_to_canon(out, &e); }
+void ref_domain_vanishing(size_t min_size, const uint64_t *t, uint64_t *out) { ref_init(); dom_t D; dom_make(&D, min_size); fr_t x; fr_from_canon(&x, t); fr_t z = dom_vanishing(&D, &x); fr_to_canon(out, &z); }
 
 /* ------------------------------------------------------------------ R1CS (CSR), synthetic instance of SURVEY 8(d) cfg 4 */
 typedef struct {
@@ -400,10 +543,10 @@ void ref_r1cs_export(void *p, int m, uint32_t *rp, uint32_t *ci, uint64_t *co) {
 }
 size_t ref_r1cs_nnz(void *p, int m) { r1cs_t *cs = (r1cs_t *)p; return cs->rp[m][cs->num_constraints]; }
 
-static unsigned domain_log(const r1cs_t *cs) {
-    size_t need = cs->num_constraints + cs->num_inputs + 1; unsigned l = 0; while (((size_t)1 << l) < need) l++; return l;
-}
-unsigned ref_r1cs_domain_log(void *p) { return domain_log((r1cs_t *)p); }
+/* r1cs_to_qap: domain = make_evaluation_domain(num_constraints + num_inputs + 1) */
+static dom_t cs_domain(const r1cs_t *cs) { dom_t D; memset(&D, 0, sizeof D); dom_make(&D, cs->num_constraints + cs->num_inputs + 1); return D; }
+size_t ref_r1cs_domain_size(void *p) { return cs_domain((r1cs_t *)p).m; }
+int ref_r1cs_domain_is_step(void *p) { return cs_domain((r1cs_t *)p).step; }
 
 static void csr_matvec(fr_t *out, const r1cs_t *cs, int m, const fr_t *zfull /* [0]=1 */) {
     for (size_t i = 0; i < cs->num_constraints; i++) {
@@ -416,27 +559,25 @@ static void csr_matvec(fr_t *out, const r1cs_t *cs, int m, const fr_t *zfull /* 
 /* r1cs_to_qap::witness_map with d1 = d2 = d3 = 0 (the values r1cs_gg_ppzksnark's prover passes):
  * returns the m coefficients of H (coefficients_for_H[0..m-1]; the (m+1)-th is 0). */
 static void witness_map_h(fr_t *H, const r1cs_t *cs, const fr_t *zfull) {
-    unsigned lm = domain_log(cs); size_t m = (size_t)1 << lm;
+    dom_t D = cs_domain(cs); size_t m = D.m;
     fr_t *aA = (fr_t *)calloc(m, sizeof(fr_t)), *aB = (fr_t *)calloc(m, sizeof(fr_t)), *aC = (fr_t *)calloc(m, sizeof(fr_t));
     csr_matvec(aA, cs, 0, zfull); csr_matvec(aB, cs, 1, zfull); csr_matvec(aC, cs, 2, zfull);
     /* the additional constraints input_i * 0 = 0 */
     for (size_t i = 0; i <= cs->num_inputs; i++) aA[cs->num_constraints + i] = zfull[i];
     fr_t g = fr_from_u64(7);
-    dom_ifft(aA, lm); dom_ifft(aB, lm);
-    dom_coset_fft(aA, lm, &g); dom_coset_fft(aB, lm, &g);
+    dom_ifft(&D, aA); dom_ifft(&D, aB);
+    dom_coset_fft(&D, aA, &g); dom_coset_fft(&D, aB, &g);
     for (size_t i = 0; i < m; i++) fr_mul(&H[i], &aA[i], &aB[i]);
-    dom_ifft(aC, lm); dom_coset_fft(aC, lm, &g);
+    dom_ifft(&D, aC); dom_coset_fft(&D, aC, &g);
     for (size_t i = 0; i < m; i++) fr_sub(&H[i], &H[i], &aC[i]);
-    /* divide_by_Z_on_coset: Z(g) = g^m - 1 */
-    fr_t zc = g; for (unsigned i = 0; i < lm; i++) fr_sqr(&zc, &zc); fr_sub(&zc, &zc, &FR_R); fr_inv(&zc, &zc);
-    for (size_t i = 0; i < m; i++) fr_mul(&H[i], &H[i], &zc);
-    dom_icoset_fft(H, lm, &g);
+    dom_divide_by_z_on_coset(&D, H, &g);
+    dom_icoset_fft(&D, H, &g);
     free(aA); free(aB); free(aC);
 }
 /* exported: Az/Bz/Cz evaluation vectors (each m x 4, zero padded, with the input rows in A) and H */
 void ref_witness_map(void *p, const uint64_t *witness /* num_vars*4 */, uint64_t *H_out /* m*4 */,
                      uint64_t *Az, uint64_t *Bz, uint64_t *Cz /* each m*4, may be NULL */) {
-    r1cs_t *cs = (r1cs_t *)p; unsigned lm = domain_log(cs); size_t m = (size_t)1 << lm;
+    r1cs_t *cs = (r1cs_t *)p; size_t m = cs_domain(cs).m;
     fr_t *z = (fr_t *)malloc((cs->num_vars + 1) * sizeof *z); z[0] = FR_R;
     for (size_t k = 1; k <= cs->num_vars; k++) fr_from_canon(&z[k], witness + 4 * (k - 1));
     if (Az && Bz && Cz) {
@@ -468,7 +609,7 @@ int ref_r1cs_is_satisfied(void *p, const uint64_t *witness) {
 
 /* ------------------------------------------------------------------ Groth16 keys (a9), generator, prover (a8) */
 typedef struct {
-    size_t num_vars, num_inputs, m; unsigned log_m;
+    size_t num_vars, num_inputs, m;
     g1_aff_t alpha_g1, beta_g1, delta_g1; g2_aff_t beta_g2, delta_g2, gamma_g2;
     g1_aff_t *A_query;             /* num_vars+1 */
     g2_aff_t *B_query_g2; g1_aff_t *B_query_g1;   /* num_vars+1 each */
@@ -481,12 +622,12 @@ typedef struct {
 void *ref_groth16_generate(void *pcs, const uint64_t *toxic /* 5*4 */) {
     r1cs_t *cs = (r1cs_t *)pcs;
     keypair_t *kp = (keypair_t *)calloc(1, sizeof *kp);
-    unsigned lm = domain_log(cs); size_t m = (size_t)1 << lm; size_t nv = cs->num_vars, ni = cs->num_inputs;
-    kp->num_vars = nv; kp->num_inputs = ni; kp->m = m; kp->log_m = lm;
+    dom_t D = cs_domain(cs); size_t m = D.m; size_t nv = cs->num_vars, ni = cs->num_inputs;
+    kp->num_vars = nv; kp->num_inputs = ni; kp->m = m;
     fr_t t, alpha, beta, gamma, delta;
     fr_from_canon(&t, toxic); fr_from_canon(&alpha, toxic + 4); fr_from_canon(&beta, toxic + 8);
     fr_from_canon(&gamma, toxic + 12); fr_from_canon(&delta, toxic + 16);
-    fr_t *u = (fr_t *)malloc(m * sizeof *u); dom_lagrange(u, lm, &t);
+    fr_t *u = (fr_t *)malloc(m * sizeof *u); dom_lagrange(&D, u, &t);
     fr_t *At = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Bt = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Ct = (fr_t *)calloc(nv + 1, sizeof(fr_t));
     for (size_t i = 0; i <= ni; i++) At[i] = u[cs->num_constraints + i];
     fr_t *Xt[3] = {At, Bt, Ct};
@@ -495,7 +636,7 @@ void *ref_groth16_generate(void *pcs, const uint64_t *toxic /* 5*4 */) {
             for (uint32_t e = cs->rp[mm][i]; e < cs->rp[mm][i + 1]; e++) {
                 fr_t x; fr_mul(&x, &u[i], &cs->co[mm][e]); fr_add(&Xt[mm][cs->ci[mm][e]], &Xt[mm][cs->ci[mm][e]], &x);
             }
-    fr_t Zt = t; for (unsigned i = 0; i < lm; i++) fr_sqr(&Zt, &Zt); fr_sub(&Zt, &Zt, &FR_R);
+    fr_t Zt = dom_vanishing(&D, &t);
     fr_t gi, di; fr_inv(&gi, &gamma); fr_inv(&di, &delta);
     /* scalars -> canonical arrays for the fixed-base batch */
     uint64_t *sc = (uint64_t *)malloc((nv + 1 + m) * 32);
@@ -534,11 +675,11 @@ void *ref_groth16_generate(void *pcs, const uint64_t *toxic /* 5*4 */) {
  * (the GPU fixed-base kernel): A_sc, B_sc [num_vars+1]; H_sc [m-1]; L_sc [num_vars-num_inputs]; ABC_sc [num_inputs+1]. */
 void ref_groth16_key_scalars(void *pcs, const uint64_t *toxic, uint64_t *A_sc, uint64_t *B_sc, uint64_t *H_sc, uint64_t *L_sc, uint64_t *ABC_sc) {
     r1cs_t *cs = (r1cs_t *)pcs;
-    unsigned lm = domain_log(cs); size_t m = (size_t)1 << lm; size_t nv = cs->num_vars, ni = cs->num_inputs;
+    dom_t D = cs_domain(cs); size_t m = D.m; size_t nv = cs->num_vars, ni = cs->num_inputs;
     fr_t t, alpha, beta, gamma, delta;
     fr_from_canon(&t, toxic); fr_from_canon(&alpha, toxic + 4); fr_from_canon(&beta, toxic + 8);
     fr_from_canon(&gamma, toxic + 12); fr_from_canon(&delta, toxic + 16);
-    fr_t *u = (fr_t *)malloc(m * sizeof *u); dom_lagrange(u, lm, &t);
+    fr_t *u = (fr_t *)malloc(m * sizeof *u); dom_lagrange(&D, u, &t);
     fr_t *At = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Bt = (fr_t *)calloc(nv + 1, sizeof(fr_t)), *Ct = (fr_t *)calloc(nv + 1, sizeof(fr_t));
     for (size_t i = 0; i <= ni; i++) At[i] = u[cs->num_constraints + i];
     fr_t *Xt[3] = {At, Bt, Ct};
@@ -547,7 +688,7 @@ void ref_groth16_key_scalars(void *pcs, const uint64_t *toxic, uint64_t *A_sc, u
             for (uint32_t e = cs->rp[mm][i]; e < cs->rp[mm][i + 1]; e++) {
                 fr_t x; fr_mul(&x, &u[i], &cs->co[mm][e]); fr_add(&Xt[mm][cs->ci[mm][e]], &Xt[mm][cs->ci[mm][e]], &x);
             }
-    fr_t Zt = t; for (unsigned i = 0; i < lm; i++) fr_sqr(&Zt, &Zt); fr_sub(&Zt, &Zt, &FR_R);
+    fr_t Zt = dom_vanishing(&D, &t);
     fr_t gi, di; fr_inv(&gi, &gamma); fr_inv(&di, &delta);
     for (size_t i = 0; i <= nv; i++) { fr_to_canon(A_sc + 4 * i, &At[i]); fr_to_canon(B_sc + 4 * i, &Bt[i]); }
     { fr_t ti = FR_R, zd; fr_mul(&zd, &Zt, &di);
