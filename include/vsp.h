@@ -126,6 +126,35 @@ int vsp_witness_map_h(vsp_ctx *ctx, uint64_t *Az, uint64_t *Bz, uint64_t *Cz /* 
                       uint64_t *H /* host m x 4 */);
 int vsp_witness_map_h_device(vsp_ctx *ctx, void *d_Az, void *d_Bz, void *d_Cz, unsigned log_m, void *d_H);
 
+/* ---- evaluation_domain<Fr> handles (a6): make_evaluation_domain, basic_radix2_domain, step_radix2_domain -----------------
+ * Replaces crypto3-math math/domains/evaluation_domain.hpp (abstract m, fft, inverse_fft, evaluate_all_lagrange_polynomials,
+ * get_domain_element, compute_vanishing_polynomial, add_poly_z, divide_by_z_on_coset), basic_radix2_domain.hpp,
+ * step_radix2_domain.hpp and math/algorithms/make_evaluation_domain.hpp (absent submodule, /root/reference/.gitmodules:47-48),
+ * which r1cs_to_qap reaches from bin/cli/include/nil/vote_saver/common.hpp:916-917 and :1132-1135.
+ * vsp_domain_create(min_size) makes the choice make_evaluation_domain makes: the basic radix-2 domain when min_size is a power of
+ * two, else the step radix-2 domain of size big + small (big = 2^(ceil_log2(min_size)-1), small = the next power of two of
+ * min_size - big), which is again basic when small == big.  extended_radix2 (m = 2^33 for this field) and the
+ * arithmetic/geometric sequence domains (Fr defines no such generators) cannot be selected for any size up to 2^28.
+ * Element order of a step domain: the big-th roots of unity w^(2i), then w * (small-th roots), w of order 2 big.
+ * NULL is returned (vsp_last_error tells why) for min_size <= 1 or > 2^28.  A domain belongs to the context's device. */
+typedef struct vsp_domain vsp_domain;
+vsp_domain *vsp_domain_create(vsp_ctx *ctx, size_t min_size);
+void vsp_domain_free(vsp_ctx *ctx, vsp_domain *dom);
+size_t vsp_domain_size(const vsp_domain *dom);                 /* m */
+int vsp_domain_kind(const vsp_domain *dom);                    /* 0 basic_radix2, 1 step_radix2 */
+/* fft / inverse_fft / coset variants, in place on m canonical values (same flags as vsp_ntt_fr) */
+int vsp_domain_fft(vsp_ctx *ctx, const vsp_domain *dom, uint64_t *a /* host m x 4 */, int inverse, const uint64_t coset_g[4]);
+int vsp_domain_fft_device(vsp_ctx *ctx, const vsp_domain *dom, void *d_a /* device m x 4 */, int inverse, const uint64_t coset_g[4]);
+/* evaluate_all_lagrange_polynomials(t): out[i] = L_i(t), m values (the indicator vector when t lies in the domain) */
+int vsp_domain_lagrange(vsp_ctx *ctx, const vsp_domain *dom, const uint64_t t[4], uint64_t *out /* host m x 4 */);
+int vsp_domain_element(vsp_ctx *ctx, const vsp_domain *dom, size_t idx, uint64_t out[4]);            /* get_domain_element */
+int vsp_domain_vanishing(vsp_ctx *ctx, const vsp_domain *dom, const uint64_t t[4], uint64_t out[4]);  /* compute_vanishing_polynomial */
+int vsp_domain_add_poly_z(vsp_ctx *ctx, const vsp_domain *dom, const uint64_t coeff[4], uint64_t *H /* host (m+1) x 4 */);
+/* divide_by_z_on_coset: P[i] /= Z(g x_i) with g the field's multiplicative generator 7 */
+int vsp_domain_divide_by_z_on_coset(vsp_ctx *ctx, const vsp_domain *dom, uint64_t *P /* host m x 4 */);
+/* witness_map over a domain handle (vsp_witness_map_h is the basic radix-2 case) */
+int vsp_domain_witness_map_h(vsp_ctx *ctx, const vsp_domain *dom, uint64_t *Az, uint64_t *Bz, uint64_t *Cz, uint64_t *H /* host m x 4 each */);
+
 /* ---- constraint system + proving key + prover (a8, a9) -------------------------------------- */
 /* Three CSR matrices over columns 0..num_vars (column 0 is the constant 1); coefficients canonical Fr. */
 vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_inputs, size_t num_vars,
@@ -133,6 +162,9 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
                           const uint32_t *row_ptr_b, const uint32_t *col_b, const uint64_t *coef_b,
                           const uint32_t *row_ptr_c, const uint32_t *col_c, const uint64_t *coef_c);
 void vsp_r1cs_free(vsp_ctx *ctx, vsp_r1cs *cs);
+/* the domain r1cs_to_qap uses for this system: make_evaluation_domain(num_constraints + num_inputs + 1); H_query has size - 1 bases */
+size_t vsp_r1cs_domain_size(const vsp_r1cs *cs);
+int vsp_r1cs_domain_kind(const vsp_r1cs *cs);                  /* 0 basic_radix2, 1 step_radix2 */
 
 /* Proving key = { alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, A_query[num_vars+1],
  * B_query (G2 and G1 halves, num_vars+1 each), H_query[m-1], L_query[num_vars-num_inputs] }

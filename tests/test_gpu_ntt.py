@@ -46,11 +46,18 @@ def test_ntt_small_vs_naive_dft(ctx):
 
 def test_ntt_rejects_bad_sizes(ctx):
     with pytest.raises(ValueError):
-        v.EvaluationDomain(ctx, 12)                      # not a power of two
+        v.EvaluationDomain(ctx, 11)                      # 8 + 3: neither a power of two nor a step size
+    with pytest.raises(ValueError):
+        v.api.BasicRadix2Domain(ctx, 12)                 # basic_radix2_domain throws unless m is a power of two
+    with pytest.raises(ValueError):
+        v.api.StepRadix2Domain(ctx, 16)
     dom = v.EvaluationDomain(ctx, 8)
     with pytest.raises(ValueError):
         dom.fft(rand_fr_array(4, 1))                     # wrong length
-    assert v.make_evaluation_domain(ctx, 9).m == 16
+    with pytest.raises(ValueError):
+        v.make_evaluation_domain(ctx, 1)
+    d9, d11, d16 = (v.make_evaluation_domain(ctx, k) for k in (9, 11, 13))
+    assert (d9.m, d9.kind, d11.m, d11.kind, d16.m, d16.kind) == (9, "step_radix2", 12, "step_radix2", 16, "basic_radix2")
 
 
 def test_ntt_full_size_properties(ctx):

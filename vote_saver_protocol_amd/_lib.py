@@ -48,6 +48,20 @@ PROTOTYPES = {
     "vsp_witness_map_h_device": (_I, [_P, _P, _P, _P, _U, _P]),
     "vsp_r1cs_upload": (_P, [_P, _SZ, _SZ, _SZ] + [_P] * 9),
     "vsp_r1cs_free": (None, [_P, _P]),
+    "vsp_r1cs_domain_size": (_SZ, [_P]),
+    "vsp_r1cs_domain_kind": (_I, [_P]),
+    "vsp_domain_create": (_P, [_P, _SZ]),
+    "vsp_domain_free": (None, [_P, _P]),
+    "vsp_domain_size": (_SZ, [_P]),
+    "vsp_domain_kind": (_I, [_P]),
+    "vsp_domain_fft": (_I, [_P, _P, _P, _I, _P]),
+    "vsp_domain_fft_device": (_I, [_P, _P, _P, _I, _P]),
+    "vsp_domain_lagrange": (_I, [_P, _P, _P, _P]),
+    "vsp_domain_element": (_I, [_P, _P, _SZ, _P]),
+    "vsp_domain_vanishing": (_I, [_P, _P, _P, _P]),
+    "vsp_domain_add_poly_z": (_I, [_P, _P, _P, _P]),
+    "vsp_domain_divide_by_z_on_coset": (_I, [_P, _P, _P]),
+    "vsp_domain_witness_map_h": (_I, [_P, _P, _P, _P, _P, _P]),
     "vsp_pk_create": (_P, [_P] * 11),
     "vsp_pk_free": (None, [_P, _P]),
     "vsp_groth16_prove": (_I, [_P] * 12),

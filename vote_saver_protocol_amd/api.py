@@ -205,21 +205,42 @@ def fold_jacobian(ctx, records, group=1):
 
 # ---- evaluation_domain (a6) -------------------------------------------------------------------
 class EvaluationDomain:
-    """math::evaluation_domain<Fr> for a power-of-two size (basic_radix2_domain).
-    Methods take and return host arrays [m,4] of canonical Fr; *_device variants work in place on
-    device memory."""
+    """math::evaluation_domain<Fr>: the basic radix-2 domain (m a power of two) or the step radix-2 domain (m = big + small,
+    both powers of two).  Methods take and return host arrays [m,4] of canonical Fr; *_device variants work in place on device
+    memory.  Method names are upstream's (crypto3-math domains/evaluation_domain.hpp); the libfqfft spellings are aliases."""
 
-    def __init__(self, ctx, m):
-        if m < 1 or m & (m - 1):
-            raise ValueError("basic_radix2_domain: m must be a power of two")   # upstream throws for other sizes
-        self.ctx, self.m, self.log_m = ctx, m, m.bit_length() - 1
+    def __init__(self, ctx, m, _min_size=None):
+        self.ctx, self.h = ctx, None
+        if m == 1 and _min_size is None:          # degenerate size kept for completeness: every transform is the identity
+            self.m, self.kind = 1, "basic_radix2"
+            return
+        self.h = ctx.lib.vsp_domain_create(ctx.h, m if _min_size is None else _min_size)
+        if not self.h:
+            raise ValueError("evaluation_domain: " + ctx.last_error())          # upstream: std::invalid_argument
+        self.m = ctx.lib.vsp_domain_size(self.h)
+        self.kind = ("basic_radix2", "step_radix2")[ctx.lib.vsp_domain_kind(self.h)]
+        if _min_size is None and self.m != m:
+            self.free()
+            raise ValueError("evaluation_domain: %d is neither a power of two nor big + small with both powers of two" % m)
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_domain_free(self.ctx.h, self.h)
+        self.h = None
+
+    def _vec(self, a, rows=None):
+        a = _u64(a, 4).copy()
+        if a.shape[0] != (self.m if rows is None else rows):
+            raise ValueError("evaluation_domain: expected vector of size m")     # upstream: std::invalid_argument
+        return a
 
     def _run(self, a, inverse, coset):
-        a = _u64(a, 4).copy()
-        if a.shape[0] != self.m:
-            raise ValueError("evaluation_domain: expected vector of size m")     # upstream: std::invalid_argument
+        a = self._vec(a)
         g = None if coset is None else _u64(coset)
-        self.ctx.check(self.ctx.lib.vsp_ntt_fr(self.ctx.h, _ptr(a), self.log_m, int(inverse), _ptr(g)))
+        if self.h is None:
+            self.ctx.check(self.ctx.lib.vsp_ntt_fr(self.ctx.h, _ptr(a), 0, int(inverse), _ptr(g)))
+        else:
+            self.ctx.check(self.ctx.lib.vsp_domain_fft(self.ctx.h, self.h, _ptr(a), int(inverse), _ptr(g)))
         return a
 
     def fft(self, a): return self._run(a, False, None)
@@ -233,27 +254,77 @@ class EvaluationDomain:
 
     def fft_device(self, d_a, inverse=False, coset=None):
         g = None if coset is None else _u64(coset)
-        self.ctx.check(self.ctx.lib.vsp_ntt_fr_device(self.ctx.h, _ptr(d_a), self.log_m, int(inverse), _ptr(g)))
+        if self.h is None:
+            self.ctx.check(self.ctx.lib.vsp_ntt_fr_device(self.ctx.h, _ptr(d_a), 0, int(inverse), _ptr(g)))
+        else:
+            self.ctx.check(self.ctx.lib.vsp_domain_fft_device(self.ctx.h, self.h, _ptr(d_a), int(inverse), _ptr(g)))
+
+    def evaluate_all_lagrange_polynomials(self, t):
+        out = np.zeros((self.m, 4), np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_domain_lagrange(self.ctx.h, self.h, _ptr(_u64(t)), _ptr(out)))
+        return out
+
+    def get_domain_element(self, idx):
+        out = np.zeros(4, np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_domain_element(self.ctx.h, self.h, idx, _ptr(out)))
+        return out
+
+    def compute_vanishing_polynomial(self, t):
+        out = np.zeros(4, np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_domain_vanishing(self.ctx.h, self.h, _ptr(_u64(t)), _ptr(out)))
+        return out
+
+    def add_poly_z(self, coeff, H):
+        H = self._vec(H, self.m + 1)
+        self.ctx.check(self.ctx.lib.vsp_domain_add_poly_z(self.ctx.h, self.h, _ptr(_u64(coeff)), _ptr(H)))
+        return H
+
+    def divide_by_z_on_coset(self, P):
+        P = self._vec(P)
+        self.ctx.check(self.ctx.lib.vsp_domain_divide_by_z_on_coset(self.ctx.h, self.h, _ptr(P)))
+        return P
+
+    def witness_map_h(self, Az, Bz, Cz):
+        Az, Bz, Cz = (self._vec(x) for x in (Az, Bz, Cz))
+        H = np.zeros((self.m, 4), np.uint64)
+        self.ctx.check(self.ctx.lib.vsp_domain_witness_map_h(self.ctx.h, self.h, _ptr(Az), _ptr(Bz), _ptr(Cz), _ptr(H)))
+        return H
 
 
-def make_evaluation_domain(ctx, min_size):
-    """math::make_evaluation_domain<Fr>(k) restricted to the radix-2 family: the smallest power of two >= k."""
-    m = 1
-    while m < min_size:
-        m *= 2
+def BasicRadix2Domain(ctx, m):
+    if m < 1 or m & (m - 1):
+        raise ValueError("basic_radix2_domain: m must be a power of two")       # upstream throws for other sizes
     return EvaluationDomain(ctx, m)
 
 
+def StepRadix2Domain(ctx, m):
+    d = EvaluationDomain(ctx, m)
+    if d.kind != "step_radix2":
+        d.free()
+        raise ValueError("step_radix2_domain: m must be big + small with small < big, both powers of two")
+    return d
+
+
+def make_evaluation_domain(ctx, min_size):
+    """math::make_evaluation_domain<Fr>(k): the first of basic_radix2(k), step_radix2(k), basic_radix2(big + rounded_small),
+    step_radix2(big + rounded_small) that exists -- the domain r1cs_to_qap works over for k = constraints + inputs + 1."""
+    return EvaluationDomain(ctx, None, _min_size=min_size)
+
+
 def witness_map_h(ctx, Az, Bz, Cz):
-    """r1cs_to_qap::witness_map tail (d1=d2=d3=0): coefficients of H from the evaluation vectors."""
-    Az, Bz, Cz = (_u64(x, 4).copy() for x in (Az, Bz, Cz))
-    m = Az.shape[0]
-    log_m = m.bit_length() - 1
-    if (1 << log_m) != m or Bz.shape[0] != m or Cz.shape[0] != m:
-        raise ValueError("witness_map: vectors must share one power-of-two length")
-    H = np.zeros((m, 4), np.uint64)
-    ctx.check(ctx.lib.vsp_witness_map_h(ctx.h, _ptr(Az), _ptr(Bz), _ptr(Cz), log_m, _ptr(H)))
-    return H
+    """r1cs_to_qap::witness_map tail (d1=d2=d3=0): coefficients of H from the evaluation vectors over the domain whose size the
+    vectors have."""
+    m = _u64(Az, 4).shape[0]
+    if m == 1:
+        Az, Bz, Cz = (_u64(x, 4).copy() for x in (Az, Bz, Cz))
+        H = np.zeros((1, 4), np.uint64)
+        ctx.check(ctx.lib.vsp_witness_map_h(ctx.h, _ptr(Az), _ptr(Bz), _ptr(Cz), 0, _ptr(H)))
+        return H
+    d = EvaluationDomain(ctx, m)
+    try:
+        return d.witness_map_h(Az, Bz, Cz)
+    finally:
+        d.free()
 
 
 # ---- Groth16 prover (a8, a9) ---------------------------------------------------------------------
@@ -275,6 +346,8 @@ class R1CS:
         if not self.h:
             raise VspError("r1cs upload failed: " + ctx.last_error())
         self._keep = None
+        self.m = ctx.lib.vsp_r1cs_domain_size(self.h)              # make_evaluation_domain(num_constraints + num_inputs + 1)
+        self.domain_kind = ("basic_radix2", "step_radix2")[ctx.lib.vsp_r1cs_domain_kind(self.h)]
 
     def free(self):
         if self.h and self.ctx.h:

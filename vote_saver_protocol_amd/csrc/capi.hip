@@ -369,25 +369,122 @@ int vsp_ntt_fr(vsp_ctx *ctx, uint64_t *a, unsigned log_m, int inverse, const uin
 int vsp_witness_map_h_device(vsp_ctx *ctx, void *d_Az, void *d_Bz, void *d_Cz, unsigned log_m, void *d_H) {
     if (!ctx) return VSP_ERR_ARG;
     if (!d_Az || !d_Bz || !d_Cz || !d_H) return set_error(ctx, VSP_ERR_ARG, "witness_map: null pointer");
+    if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "witness_map: log_m > 28");
     VSP_HIP(hipSetDevice(ctx->device));
-    return witness_map_device(ctx, (Fr *)d_Az, (Fr *)d_Bz, (Fr *)d_Cz, log_m, (Fr *)d_H);
+    vsp_domain d; domain_basic(&d, log_m);
+    return witness_map_device(ctx, (Fr *)d_Az, (Fr *)d_Bz, (Fr *)d_Cz, &d, (Fr *)d_H);
+}
+static int witness_map_host(vsp_ctx *ctx, const vsp_domain *d, uint64_t *Az, uint64_t *Bz, uint64_t *Cz, uint64_t *H) {
+    size_t bytes = d->m * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_a, bytes)); VSP_TRY(ensure(ctx, ctx->pr_b, bytes));
+    VSP_TRY(ensure(ctx, ctx->pr_c, bytes)); VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_a.p, Az, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_b.p, Bz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_c.p, Cz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_TRY(witness_map_device(ctx, (Fr *)ctx->pr_a.p, (Fr *)ctx->pr_b.p, (Fr *)ctx->pr_c.p, d, (Fr *)ctx->pr_h.p));
+    VSP_HIP(hipMemcpyAsync(H, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
 }
 int vsp_witness_map_h(vsp_ctx *ctx, uint64_t *Az, uint64_t *Bz, uint64_t *Cz, unsigned log_m, uint64_t *H) {
     if (!ctx) return VSP_ERR_ARG;
     if (!Az || !Bz || !Cz || !H) return set_error(ctx, VSP_ERR_ARG, "witness_map: null pointer");
     if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "witness_map: log_m > 28");
     VSP_HIP(hipSetDevice(ctx->device));
-    size_t bytes = ((size_t)1 << log_m) * 32;
-    VSP_TRY(ensure(ctx, ctx->pr_a, bytes)); VSP_TRY(ensure(ctx, ctx->pr_b, bytes));
-    VSP_TRY(ensure(ctx, ctx->pr_c, bytes)); VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
-    VSP_HIP(hipMemcpyAsync(ctx->pr_a.p, Az, bytes, hipMemcpyHostToDevice, ctx->stream));
-    VSP_HIP(hipMemcpyAsync(ctx->pr_b.p, Bz, bytes, hipMemcpyHostToDevice, ctx->stream));
-    VSP_HIP(hipMemcpyAsync(ctx->pr_c.p, Cz, bytes, hipMemcpyHostToDevice, ctx->stream));
-    VSP_TRY(witness_map_device(ctx, (Fr *)ctx->pr_a.p, (Fr *)ctx->pr_b.p, (Fr *)ctx->pr_c.p, log_m, (Fr *)ctx->pr_h.p));
-    VSP_HIP(hipMemcpyAsync(H, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    vsp_domain d; domain_basic(&d, log_m);
+    return witness_map_host(ctx, &d, Az, Bz, Cz, H);
+}
+
+// ---- evaluation_domain<Fr> handles: make_evaluation_domain, basic and step radix-2 ---------------------------------
+vsp_domain *vsp_domain_create(vsp_ctx *ctx, size_t min_size) {
+    if (!ctx) return nullptr;
+    hipSetDevice(ctx->device);
+    vsp_domain *d = new vsp_domain();
+    if (domain_init(ctx, d, min_size) != VSP_OK) { domain_release(d); delete d; return nullptr; }
+    return d;
+}
+void vsp_domain_free(vsp_ctx *ctx, vsp_domain *d) {
+    if (!d) return;
+    if (ctx) hipSetDevice(ctx->device);
+    domain_release(d);
+    delete d;
+}
+size_t vsp_domain_size(const vsp_domain *d) { return d ? d->m : 0; }
+int vsp_domain_kind(const vsp_domain *d) { return d ? d->step : -1; }
+int vsp_domain_fft_device(vsp_ctx *ctx, const vsp_domain *d, void *d_a, int inverse, const uint64_t coset_g[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !d_a) return set_error(ctx, VSP_ERR_ARG, "domain_fft: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    return domain_fft_device(ctx, d, (Fr *)d_a, inverse, coset_g, nullptr);
+}
+int vsp_domain_fft(vsp_ctx *ctx, const vsp_domain *d, uint64_t *a, int inverse, const uint64_t coset_g[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !a) return set_error(ctx, VSP_ERR_ARG, "domain_fft: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t bytes = d->m * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_h.p, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_TRY(domain_fft_device(ctx, d, (Fr *)ctx->pr_h.p, inverse, coset_g, nullptr));
+    VSP_HIP(hipMemcpyAsync(a, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VSP_HIP(hipStreamSynchronize(ctx->stream));
     return VSP_OK;
 }
+int vsp_domain_lagrange(vsp_ctx *ctx, const vsp_domain *d, const uint64_t t[4], uint64_t *out) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !t || !out) return set_error(ctx, VSP_ERR_ARG, "domain_lagrange: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t bytes = d->m * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_TRY(domain_lagrange_device(ctx, d, host_load_canon<HFr>(t), (Fr *)ctx->pr_h.p));
+    VSP_TRY(fr_from_mont_device(ctx, (Fr *)ctx->pr_h.p, d->m));
+    VSP_HIP(hipMemcpyAsync(out, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+int vsp_domain_element(vsp_ctx *ctx, const vsp_domain *d, size_t idx, uint64_t out[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !out || idx >= d->m) return set_error(ctx, VSP_ERR_ARG, "domain_element: bad argument");
+    host_store_canon(out, domain_element(d, idx));
+    return VSP_OK;
+}
+int vsp_domain_vanishing(vsp_ctx *ctx, const vsp_domain *d, const uint64_t t[4], uint64_t out[4]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !t || !out) return set_error(ctx, VSP_ERR_ARG, "domain_vanishing: null pointer");
+    host_store_canon(out, domain_vanishing(d, host_load_canon<HFr>(t)));
+    return VSP_OK;
+}
+// H (m + 1 coefficients, host, canonical) += coeff * Z
+int vsp_domain_add_poly_z(vsp_ctx *ctx, const vsp_domain *d, const uint64_t coeff[4], uint64_t *H) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !coeff || !H) return set_error(ctx, VSP_ERR_ARG, "domain_add_poly_z: null pointer");
+    HFr c = host_load_canon<HFr>(coeff);
+    auto upd = [&](size_t i, const HFr &delta) { HFr v = host_load_canon<HFr>(H + 4 * i); host_store_canon(H + 4 * i, add(v, delta)); };
+    if (!d->step) { upd(d->m, c); upd(0, neg(c)); return VSP_OK; }
+    uint64_t e[1] = {(uint64_t)d->small_m};
+    HFr cw = mul(c, pow_limbs(host_omega(d->log_big + 1), e, 1));
+    upd(d->m, c); upd(d->big_m, neg(cw)); upd(d->small_m, neg(c)); upd(0, cw);
+    return VSP_OK;
+}
+int vsp_domain_divide_by_z_on_coset(vsp_ctx *ctx, const vsp_domain *d, uint64_t *P) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !P) return set_error(ctx, VSP_ERR_ARG, "domain_divide_by_z_on_coset: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    size_t bytes = d->m * 32;
+    VSP_TRY(ensure(ctx, ctx->pr_h, bytes));
+    VSP_HIP(hipMemcpyAsync(ctx->pr_h.p, P, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VSP_TRY(domain_divide_by_z_device(ctx, d, (Fr *)ctx->pr_h.p));
+    VSP_HIP(hipMemcpyAsync(P, ctx->pr_h.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    return VSP_OK;
+}
+int vsp_domain_witness_map_h(vsp_ctx *ctx, const vsp_domain *d, uint64_t *Az, uint64_t *Bz, uint64_t *Cz, uint64_t *H) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!d || !Az || !Bz || !Cz || !H) return set_error(ctx, VSP_ERR_ARG, "witness_map: null pointer");
+    VSP_HIP(hipSetDevice(ctx->device));
+    return witness_map_host(ctx, d, Az, Bz, Cz, H);
+}
+size_t vsp_r1cs_domain_size(const vsp_r1cs *cs) { return cs ? cs->dom.m : 0; }
+int vsp_r1cs_domain_kind(const vsp_r1cs *cs) { return cs ? cs->dom.step : -1; }
 
 // ---- generator-side batch exponentiation ---------------------------------------------------------
 int vsp_fixed_base_mul_g1(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d_out) {

@@ -75,6 +75,7 @@ struct vsp_ctx {
     std::map<std::string, long> opts;
     vsp::NttTables ntt;
     vsp::DevBuf ntt_scratch;
+    vsp::DevBuf dom_scratch;            // step-domain transforms: the d / partial-sum vectors
     // MSM work slots (slot 0 runs on the context's stream; the others own a stream each)
     vsp::MsmWork msm_work[vsp::VSP_MSM_SLOTS];
     int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
@@ -94,9 +95,21 @@ struct vsp_bases {
     unsigned pre_c = 0;
 };
 
+// math::evaluation_domain<Fr>: the basic radix-2 domain (step = 0, m = big_m = 2^log_big) or the step radix-2 domain
+// (m = big_m + small_m, both powers of two, small_m < big_m) that make_evaluation_domain(min_size) selects
+struct vsp_domain {
+    size_t m = 0, big_m = 0, small_m = 0;
+    unsigned log_big = 0, log_small = 0;
+    int step = 0;
+    // divide_by_z_on_coset for the coset generator 7: 1 / Z(7 x_i).  Basic domain: one constant.  Step domain: a table of period
+    // compr = big_m / small_m over the first big_m elements (device, Montgomery form) and one constant for the last small_m.
+    vsp::DevBuf zinv;
+    vsp::HFr zinv_const;
+};
+
 struct vsp_r1cs {
     size_t num_constraints = 0, num_inputs = 0, num_vars = 0;
-    unsigned log_m = 0;
+    vsp_domain dom;          // make_evaluation_domain(num_constraints + num_inputs + 1)
     uint32_t *rp[3] = {nullptr, nullptr, nullptr};
     uint32_t *ci[3] = {nullptr, nullptr, nullptr};
     void *co[3] = {nullptr, nullptr, nullptr};      // Fr Montgomery
@@ -138,7 +151,19 @@ int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
 
 // ---- internal entry points (each implemented in its own .hip) ----
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
-int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr *dH);
+int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m);
+int ntt_ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4);
+// evaluation domains (domain.hip)
+int domain_init(vsp_ctx *ctx, vsp_domain *d, size_t min_size);      // make_evaluation_domain's choice + the coset divisors
+void domain_release(vsp_domain *d);
+void domain_basic(vsp_domain *d, unsigned log_m);                   // the basic radix-2 domain of size 2^log_m (log_m = 0 allowed)
+int fr_from_mont_device(vsp_ctx *ctx, Fr *d_a, size_t n);
+int domain_fft_device(vsp_ctx *ctx, const vsp_domain *d, Fr *d_a, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+int domain_divide_by_z_device(vsp_ctx *ctx, const vsp_domain *d, Fr *d_p);
+int domain_lagrange_device(vsp_ctx *ctx, const vsp_domain *d, const HFr &t, Fr *d_u /* m, Montgomery form */);
+HFr domain_vanishing(const vsp_domain *d, const HFr &t);
+HFr domain_element(const vsp_domain *d, size_t idx);
+int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, const vsp_domain *d, Fr *dH);
 
 // MSM on device-resident Montgomery bases; result as host XYZZ (Montgomery, 64-bit limbs)
 int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);

@@ -3,7 +3,7 @@
 // Replaces, as the first "next" row of SURVEY.md 8(f), zk::generate<proof_system>(r1cs) of crypto3-zk (absent submodule,
 // /root/reference/.gitmodules:11-12), called at bin/cli/include/nil/vote_saver/common.hpp:916-917 -- the multi-minute CPU
 // setup of the reference.  Steps (libsnark r1cs_to_qap::instance_map_with_evaluation + r1cs_gg_ppzksnark_generator lineage):
-//   u_j   = L_j(t) for the radix-2 domain        (k_lagrange: one batched inversion per 32 elements)
+//   u_j   = L_j(t) over the constraint system's domain, basic or step radix-2  (domain.hip: one batched inversion per 32 elements)
 //   A_i(t), B_i(t), C_i(t) = sum_j coef_{j,i} u_j  (k_qap_columns: one thread per variable over a column-major copy)
 //   exponents: A_i, B_i, t^i Z(t)/delta, (beta A_i + alpha B_i + C_i)/delta | /gamma
 //   queries = exponent * generator               (vsp_fixed_base_mul: 8-bit windowed fixed-base, batch normalisation)
@@ -13,38 +13,8 @@ namespace vsp {
 namespace {
 
 static constexpr unsigned GEN_PW = 11;          // two-level power tables: x^i = lo[i & 2047] * hi[i >> 11]
-static constexpr unsigned LG_CHUNK = 32;
 
-struct GenConsts { Fr t, l0, alpha, beta, gamma_inv, delta_inv, zt_delta_inv; };
-
-// u[j] = l0 * w^j / (t - w^j), l0 = Z(t)/m  (Montgomery form); requires Z(t) != 0
-__global__ __launch_bounds__(64) void k_lagrange(const Fr *w_lo, const Fr *w_hi, const GenConsts *kc, size_t m, Fr *pre, Fr *u) {
-    const Fr k_t = kc->t, k_l0 = kc->l0;
-    size_t th = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t b = th * LG_CHUNK, e = b + LG_CHUNK < m ? b + LG_CHUNK : m;
-    if (b >= m) return;
-    Fr acc = Fr::one();
-    for (size_t j = b; j < e; j++) {
-        Fr w = mul(w_lo[j & ((1u << GEN_PW) - 1u)], w_hi[j >> GEN_PW]);
-        pre[j] = acc;
-        acc = mul(acc, sub(k_t, w));
-    }
-    Fr ai = inv(acc);
-    for (size_t j = e; j-- > b;) {
-        Fr w = mul(w_lo[j & ((1u << GEN_PW) - 1u)], w_hi[j >> GEN_PW]);    // recomputed (parking it in u[] trips a compiler crash)
-        Fr di = mul(ai, pre[j]);                          // 1 / (t - w^j)
-        ai = mul(ai, sub(k_t, w));
-        u[j] = mul(mul(k_l0, w), di);
-    }
-}
-// t lies in the domain: u is the indicator of w^j == t
-__global__ __launch_bounds__(256) void k_lagrange_onehot(const Fr *w_lo, const Fr *w_hi, const GenConsts *kc, size_t m, Fr *u) {
-    const Fr k_t = kc->t;
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    Fr w = mul(w_lo[j & ((1u << GEN_PW) - 1u)], w_hi[j >> GEN_PW]);
-    u[j] = eq(w, k_t) ? Fr::one() : Fr::zero();
-}
+struct GenConsts { Fr alpha, beta, gamma_inv, delta_inv, zt_delta_inv; };
 
 // X_i(t) = sum over the column's entries of coef * u[row]   (+ u[nc + i] for the input rows of A)
 __global__ __launch_bounds__(256) void k_qap_columns(const uint32_t *cp, const uint32_t *ri, const Fr *cot, const Fr *u, size_t ncols,
@@ -117,43 +87,34 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
     hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints, ncols = nv + 1;
-    const unsigned lm = cs->log_m; const size_t m = (size_t)1 << lm;
+    const size_t m = cs->dom.m;
     HFr t = host_load_canon<HFr>(toxic), alpha = host_load_canon<HFr>(toxic + 4), beta = host_load_canon<HFr>(toxic + 8);
     HFr gamma = host_load_canon<HFr>(toxic + 12), delta = host_load_canon<HFr>(toxic + 16);
     if (is_zero(gamma) || is_zero(delta)) { set_error(ctx, VSP_ERR_ARG, "generate: gamma and delta must be non-zero"); return nullptr; }
-    HFr tm = t; for (unsigned i = 0; i < lm; i++) tm = sqr(tm);
-    HFr Zt = sub(tm, HFr::one());
-    uint64_t m4[4] = {(uint64_t)m, 0, 0, 0};
-    HFr minv = inv(host_load_canon<HFr>(m4));
+    HFr Zt = domain_vanishing(&cs->dom, t);
     GenConsts k;
-    k.t = dev(t); k.l0 = dev(mul(Zt, minv)); k.alpha = dev(alpha); k.beta = dev(beta);
+    k.alpha = dev(alpha); k.beta = dev(beta);
     k.gamma_inv = dev(inv(gamma)); k.delta_inv = dev(inv(delta)); k.zt_delta_inv = dev(mul(Zt, inv(delta)));
 
-    DevBuf w_lo, w_hi, t_lo, t_hi, u, pre, At, Bt, Ct, A_sc, B_sc, H_sc, L_sc, ABC_sc, pts, kbuf;
+    DevBuf t_lo, t_hi, u, At, Bt, Ct, A_sc, B_sc, H_sc, L_sc, ABC_sc, pts, kbuf;
     vsp_keypair *kp = new vsp_keypair();
     auto fail = [&](const char *msg) -> vsp_keypair * {
         if (msg) set_error(ctx, VSP_ERR_HIP, msg);
-        DevBuf *all[] = {&w_lo, &w_hi, &t_lo, &t_hi, &u, &pre, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc, &pts, &kbuf};
+        DevBuf *all[] = {&t_lo, &t_hi, &u, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc, &pts, &kbuf};
         for (DevBuf *b : all) free_dev(*b);
         vsp_keypair_free(ctx, kp);
         return nullptr;
     };
-    const size_t hi_count = m > ((size_t)1 << GEN_PW) ? (m >> GEN_PW) : 1;
-    if (upload_power_tables(ctx, host_omega(lm), hi_count, w_lo, w_hi) != VSP_OK) return fail(nullptr);
+    const size_t hi_count = (m + ((size_t)1 << GEN_PW) - 1) >> GEN_PW;     // m need not be a power of two (step domain)
     if (upload_power_tables(ctx, t, hi_count, t_lo, t_hi) != VSP_OK) return fail(nullptr);
-    size_t sizes[] = {m, m, ncols, ncols, ncols, ncols, ncols, m, nv - ni + 1, ni + 1};
-    DevBuf *bufs[] = {&u, &pre, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc};
-    for (int i = 0; i < 10; i++) if (ensure(ctx, *bufs[i], sizes[i] * sizeof(Fr)) != VSP_OK) return fail(nullptr);
+    size_t sizes[] = {m, ncols, ncols, ncols, ncols, ncols, m, nv - ni + 1, ni + 1};
+    DevBuf *bufs[] = {&u, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc};
+    for (int i = 0; i < 9; i++) if (ensure(ctx, *bufs[i], sizes[i] * sizeof(Fr)) != VSP_OK) return fail(nullptr);
 
     if (ensure(ctx, kbuf, sizeof(GenConsts)) != VSP_OK) return fail(nullptr);
     if (hipMemcpyAsync(kbuf.p, &k, sizeof(GenConsts), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("generate: constants upload failed");
     const GenConsts *kd = (const GenConsts *)kbuf.p;
-    if (!is_zero(Zt)) {
-        size_t chunks = (m + LG_CHUNK - 1) / LG_CHUNK;
-        hipLaunchKernelGGL(k_lagrange, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, (const Fr *)w_lo.p, (const Fr *)w_hi.p, kd, m, (Fr *)pre.p, (Fr *)u.p);
-    } else {
-        hipLaunchKernelGGL(k_lagrange_onehot, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, (const Fr *)w_lo.p, (const Fr *)w_hi.p, kd, m, (Fr *)u.p);
-    }
+    if (domain_lagrange_device(ctx, &cs->dom, t, (Fr *)u.p) != VSP_OK) return fail(nullptr);
     const unsigned cblk = (unsigned)((ncols + 255) / 256);
     Fr *Xt[3] = {(Fr *)At.p, (Fr *)Bt.p, (Fr *)Ct.p};
     for (int mm = 0; mm < 3; mm++)
@@ -184,7 +145,7 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
     mul2(toxic + 8, kp->beta_g2); mul2(toxic + 16, kp->delta_g2); mul2(toxic + 12, kp->gamma_g2);
     kp->pk = vsp_pk_create(ctx, kp->alpha_g1, kp->beta_g1, kp->beta_g2, kp->delta_g1, kp->delta_g2, kp->q[0], kp->q[1], kp->q[2], kp->q[3], kp->q[4]);
     if (!kp->pk || hipStreamSynchronize(st) != hipSuccess) return fail("generate: failed");
-    DevBuf *all[] = {&w_lo, &w_hi, &t_lo, &t_hi, &u, &pre, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc, &pts, &kbuf};
+    DevBuf *all[] = {&t_lo, &t_hi, &u, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc, &pts, &kbuf};
     for (DevBuf *b : all) free_dev(*b);
     return kp;
 }

@@ -1,4 +1,4 @@
-// Radix-2 NTT over BLS12-381 Fr for gfx950, plus the pointwise kernels of r1cs_to_qap::witness_map.
+// Radix-2 NTT over BLS12-381 Fr for gfx950 (the step radix-2 domain and witness_map built on it are in domain.hip).
 //
 // Replaces math::evaluation_domain<Fr> / basic_radix2_domain (fft, inverse_fft, coset variants,
 // divide_by_z_on_coset) of crypto3-math -- absent submodule, /root/reference/.gitmodules:47-48;
@@ -7,7 +7,7 @@
 // (libfqfft _basic_serial_radix2_FFT); the output is the DFT, unique given omega.
 //
 // MI355X design:
-//  * The log2(m) stages are grouped into passes of <= 8 stages.  One workgroup (256 threads) owns a
+//  * The log2(m) stages are grouped into passes of <= 8 stages.  One workgroup (512 threads) owns a
 //    tile of 2048 elements (64 KiB of LDS, two workgroups per CU), runs all of the pass's stages out
 //    of LDS and touches HBM exactly once for read and once for write: traffic per pass = 64 B/element,
 //    2-4 passes per transform (m = 2^22: 3 passes, 8+7+7 stages).
@@ -130,15 +130,6 @@ __global__ __launch_bounds__(256) void k_fill_twiddles(Fr *T, const Fr *A, const
     if (j < count) T[j] = mul(A[j & ((1u << PW_LOG) - 1u)], B[j >> PW_LOG]);
 }
 
-// ---- pointwise kernels of witness_map --------------------------------------------------------
-// h[i] = montmul(a[i], b[i]) - montmul(c[i], 1) = (a*b - c) / R  (canonical a, b, c).  The missing
-// factor R, the divide_by_z_on_coset constant 1/Z(g) and m^-1 are folded into the scale constant of
-// the inverse coset transform that follows, so this stays at two products per element.
-__global__ __launch_bounds__(256) void k_ab_minus_c(Fr *h, const Fr *a, const Fr *b, const Fr *c, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) h[i] = sub(mul(a[i], b[i]), mul(c[i], Fr::raw_one()));
-}
-
 // ---- host side ----------------------------------------------------------------------------------
 static const uint64_t FR_ROOT_2_32[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL};
 
@@ -168,7 +159,7 @@ int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &
     return VSP_OK;
 }
 
-static int ensure_twiddles(vsp_ctx *ctx, unsigned log_m) {
+int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m) {
     NttTables &t = ctx->ntt;
     if (t.log >= log_m && t.fwd.p) return VSP_OK;
     unsigned lg = log_m < 1 ? 1 : log_m;
@@ -191,7 +182,7 @@ static int ensure_twiddles(vsp_ctx *ctx, unsigned log_m) {
     return VSP_OK;
 }
 
-static int ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4) {
+int ntt_ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4) {
     NttTables &t = ctx->ntt;
     if (t.pw_valid && t.pw_log >= log_m && memcmp(t.pw_g, g4, 32) == 0) return VSP_OK;
     size_t n = (size_t)1 << log_m;
@@ -211,8 +202,8 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
         uint64_t z = coset_g[0] | coset_g[1] | coset_g[2] | coset_g[3];
         if (!z) return set_error(ctx, VSP_ERR_ARG, "ntt: coset generator is zero");
     }
-    VSP_TRY(ensure_twiddles(ctx, log_m));
-    if (coset_g) VSP_TRY(ensure_coset_tables(ctx, log_m, coset_g));
+    VSP_TRY(ntt_ensure_twiddles(ctx, log_m));
+    if (coset_g) VSP_TRY(ntt_ensure_coset_tables(ctx, log_m, coset_g));
     const size_t n = (size_t)1 << log_m;
 
     // pass plan
@@ -259,28 +250,6 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
         // m = 1: the transform is the identity; only an explicit extra scale would matter (not used)
     }
     ctx->stats["ntt_passes"] = (double)npass;
-    return VSP_OK;
-}
-
-// r1cs_to_qap::witness_map, d1 = d2 = d3 = 0:  H = icosetFFT( (cosetFFT(iFFT(A)) * cosetFFT(iFFT(B)) - cosetFFT(iFFT(C))) / Z(g) )
-// dA, dB, dC: m canonical values each (overwritten); dH receives the m coefficients of H.
-int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, unsigned log_m, Fr *dH) {
-    static const uint64_t G7[4] = {7, 0, 0, 0};
-    const size_t m = (size_t)1 << log_m;
-    Fr *v[3] = {dA, dB, dC};
-    for (int k = 0; k < 3; k++) {
-        VSP_TRY(ntt_device(ctx, v[k], log_m, 1, nullptr, nullptr));
-        VSP_TRY(ntt_device(ctx, v[k], log_m, 0, G7, nullptr));
-    }
-    unsigned blocks = (unsigned)((m + 255) / 256);
-    hipLaunchKernelGGL(k_ab_minus_c, dim3(blocks), dim3(256), 0, ctx->stream, dH, (const Fr *)dA, (const Fr *)dB, (const Fr *)dC, m);
-    VSP_LAUNCH_CHECK();
-    // fold: R (from the plain Montgomery products above) * 1/Z(g),  Z(g) = g^m - 1
-    HFr g = host_from_u64(7), zc = g;
-    for (unsigned i = 0; i < log_m; i++) zc = sqr(zc);
-    zc = inv(sub(zc, HFr::one()));
-    HFr extra = mul(zc, HFr::r2());      // value zc * R in Montgomery form  (Mont(R) = R^2 mod r)
-    VSP_TRY(ntt_device(ctx, dH, log_m, 1, G7, &extra));
     return VSP_OK;
 }
 

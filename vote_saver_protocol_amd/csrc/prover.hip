@@ -44,7 +44,7 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
     hipSetDevice(ctx->device);
     vsp_r1cs *cs = new vsp_r1cs();
     cs->num_constraints = num_constraints; cs->num_inputs = num_inputs; cs->num_vars = num_vars;
-    cs->log_m = ceil_log2(num_constraints + num_inputs + 1);
+    if (domain_init(ctx, &cs->dom, num_constraints + num_inputs + 1) != VSP_OK) { delete cs; return nullptr; }
     const uint32_t *rp[3] = {row_ptr_a, row_ptr_b, row_ptr_c}, *ci[3] = {col_a, col_b, col_c};
     const uint64_t *co[3] = {coef_a, coef_b, coef_c};
     for (int m = 0; m < 3; m++) {
@@ -84,6 +84,7 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
 void vsp_r1cs_free(vsp_ctx *ctx, vsp_r1cs *cs) {
     if (!cs) return;
     if (ctx) hipSetDevice(ctx->device);
+    domain_release(&cs->dom);
     for (int m = 0; m < 3; m++) {
         if (cs->rp[m]) hipFree(cs->rp[m]); if (cs->ci[m]) hipFree(cs->ci[m]); if (cs->co[m]) hipFree(cs->co[m]);
         if (cs->cp[m]) hipFree(cs->cp[m]); if (cs->ri[m]) hipFree(cs->ri[m]); if (cs->cot[m]) hipFree(cs->cot[m]);
@@ -114,7 +115,7 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     if (!ctx) return VSP_ERR_ARG;
     if (!cs || !pk || !witness || !r || !s) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints;
-    const unsigned lm = cs->log_m; const size_t m = (size_t)1 << lm;
+    const size_t m = cs->dom.m;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
         return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
     VSP_HIP(hipSetDevice(ctx->device));
@@ -154,7 +155,7 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     // option "prove_h_first" (default 1): queue witness_map + H before the witness multi-exponentiations, or after (0)
     long h_first = 1; { auto it = ctx->opts.find("prove_h_first"); if (it != ctx->opts.end()) h_first = it->second; }
     if (h_first) {
-        VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+        VSP_TRY(witness_map_device(ctx, dA, dB, dC, &cs->dom, dH));
         VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
     }
     {
@@ -169,7 +170,7 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     VSP_TRY(launch_on_bases(ctx, 2, pk->B1, 0, nv + 1, dz, pk->B1->pre_c == pk->A->pre_c ? 1 : -1));
     VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, -1));
     if (!h_first) {
-        VSP_TRY(witness_map_device(ctx, dA, dB, dC, lm, dH));
+        VSP_TRY(witness_map_device(ctx, dA, dB, dC, &cs->dom, dH));
         VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));
     }
     lap("prove_launch_ms");
