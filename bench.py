@@ -50,6 +50,37 @@ def limbs(v, n):
     return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
 
 
+def bench_prove_step_domain(ctx, v, cref, o, precompute=True):
+    """A constraint count that is not a power of two, as the reference's real circuit has: 2^20 + 2^17 - 32 constraints.
+    make_evaluation_domain selects the step radix-2 domain of 2^20 + 2^17 elements (a power-of-two-only prover would pay for
+    2^21).  GPU generator, prove, pairing check."""
+    import pairing as pg
+    ni = 30
+    nc = (1 << 20) + (1 << 17) - ni - 2
+    gen = o.splitmix64(15)
+    cs, wit = cref.R1CS.synth(nc, ni, 14)
+    tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
+    A, B, Cm = cs.export()
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
+    kp = v.Keypair(ctx, dcs, tox, precompute=precompute)
+    r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
+    pa, pb, pc, _ = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pa, pb, pc, _ = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_)
+    dt = (time.perf_counter() - t0) / reps
+    vk = dict(alpha_g1=o.g1_from_limbs(kp.part("alpha_g1")[0]), beta_g2=o.g2_from_limbs(kp.part("beta_g2")[0]),
+              gamma_g2=o.g2_from_limbs(kp.part("gamma_g2")[0]), delta_g2=o.g2_from_limbs(kp.part("delta_g2")[0]),
+              gamma_ABC_g1=[o.g1_from_limbs(x) for x in kp.part("gamma_ABC_g1")])
+    pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
+    ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
+    out = {"prove_step_domain_constraints": nc, "prove_step_domain_m": int(dcs.m), "prove_step_domain_kind": dcs.domain_kind,
+           "prove_step_domain_ms": dt * 1e3, "prove_step_domain_pairing_verified": bool(ok)}
+    kp.free(); dcs.free(); cs.free()
+    return out
+
+
 def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     """BASELINE config 4: full r1cs_gg_ppzksnark prove on a synthetic satisfiable R1CS filling a 2^log_m domain
     (90 % boolean wires, 30 public inputs).  The proving key is built on the GPU (generator batch
@@ -341,6 +372,7 @@ def main():
 
         if world == 1 and not args.no_prove:
             extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=not args.no_precompute))
+            extras.update(bench_prove_step_domain(ctx, v, cref, o, precompute=not args.no_precompute))
 
     ctx.dfree(d_bases_canon)
     total_points = n * world * args.steps

@@ -27,11 +27,30 @@ int main() {
     try {
         G1pt r = vsp::multiexp<vsp::policies::multiexp_method_BDLO12>(bases.begin(), bases.end(), scalars.begin(), scalars.end(), 1);
         std::printf("2G.x[0] = %016llx\n", (unsigned long long)r.x.l[0]);
-        auto dom = vsp::make_evaluation_domain<Fr4>(5);
-        std::vector<Fr4> a(dom->m);
-        for (std::size_t i = 0; i < a.size(); i++) a[i] = Fr4{{i + 1, 0, 0, 0}};
-        auto b = a; dom->fft(b); dom->inverse_fft(b);
-        std::printf("roundtrip %s\n", b == a ? "ok" : "MISMATCH");
-        return b == a ? 0 : 1;
+        bool ok = true;
+        for (std::size_t min_size : {5, 8, 11, 70}) {          // 5 -> 5 (step 4+1), 8 -> 8 (basic), 11 -> 12 (step 8+4), 70 -> 72 (step 64+8)
+            auto dom = vsp::make_evaluation_domain<Fr4>(min_size);
+            std::vector<Fr4> a(dom->m);
+            for (std::size_t i = 0; i < a.size(); i++) a[i] = Fr4{{i + 1, 0, 0, 0}};
+            auto b = a; dom->fft(b); dom->inverse_fft(b);
+            auto c = a; Fr4 g{{7, 0, 0, 0}}; dom->cosetFFT(c, g); dom->icosetFFT(c, g);
+            // L_i(x_k) is the indicator of i == k;  Z vanishes on the domain
+            Fr4 x3 = dom->get_domain_element(3);
+            auto u = dom->evaluate_all_lagrange_polynomials(x3);
+            bool ind = true;
+            for (std::size_t i = 0; i < u.size(); i++) ind = ind && (u[i] == Fr4{{i == 3 ? 1ull : 0ull, 0, 0, 0}});
+            Fr4 z = dom->compute_vanishing_polynomial(x3);
+            // add_poly_z then evaluate nothing: just the shape (m + 1 coefficients); divide_by_z_on_coset keeps the size
+            std::vector<Fr4> H(dom->m + 1, Fr4{{0, 0, 0, 0}}); dom->add_poly_z(Fr4{{1, 0, 0, 0}}, H);
+            auto P = a; dom->divide_by_z_on_coset(P);
+            bool good = b == a && c == a && ind && z == Fr4{{0, 0, 0, 0}} && H[dom->m] == Fr4{{1, 0, 0, 0}} && P.size() == dom->m;
+            std::printf("domain(min %zu) m=%zu %s: %s\n", min_size, dom->m, dom->is_step_radix2() ? "step_radix2" : "basic_radix2", good ? "ok" : "MISMATCH");
+            ok = ok && good;
+        }
+        bool threw = false;
+        try { vsp::basic_radix2_domain<Fr4> bad(12); } catch (const std::invalid_argument &) { threw = true; }
+        try { vsp::step_radix2_domain<Fr4> s12(12); ok = ok && s12.m == 12; } catch (const std::invalid_argument &) { ok = false; }
+        std::printf("roundtrip %s\n", ok && threw ? "ok" : "MISMATCH");
+        return ok && threw ? 0 : 1;
     } catch (const std::exception &e) { std::printf("no GPU path: %s\n", e.what()); return 77; }
 }
