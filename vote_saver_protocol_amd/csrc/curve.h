@@ -42,7 +42,7 @@ template <class F> VSP_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
     F M = add(dbl(XX), XX);
     XYZZ<F> r;
     r.X = sub(sqr(M), dbl(S));
-    r.Y = sub(mul(M, sub(S, r.X)), mul(W, p.Y));
+    r.Y = mul_add2(M, sub(S, r.X), neg(W), p.Y);
     r.ZZ = mul(V, p.ZZ);
     r.ZZZ = mul(W, p.ZZZ);
     return r;       // Y = 0 cannot occur: the groups have odd order
@@ -58,7 +58,7 @@ template <class F> VSP_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
     F M = add(dbl(XX), XX);
     XYZZ<F> r;
     r.X = sub(sqr(M), dbl(S));
-    r.Y = sub(mul(M, sub(S, r.X)), mul(W, p.y));
+    r.Y = mul_add2(M, sub(S, r.X), neg(W), p.y);
     r.ZZ = V;
     r.ZZZ = W;
     return r;
@@ -83,7 +83,7 @@ template <class F> VSP_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bo
     F PPP = mul(P, PP);
     F Q = mul(acc.X, PP);
     F X3 = sub(sub(sqr(R), PPP), dbl(Q));
-    acc.Y = sub(mul(R, sub(Q, X3)), mul(acc.Y, PPP));
+    acc.Y = mul_add2(R, sub(Q, X3), neg(acc.Y), PPP);        // R (Q - X3) - Y1 PPP, one reduction
     acc.X = X3;
     acc.ZZ = mul(acc.ZZ, PP);
     acc.ZZZ = mul(acc.ZZZ, PPP);
@@ -108,7 +108,7 @@ template <class F> VSP_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
     F PPP = mul(P, PP);
     F Q = mul(U1, PP);
     F X3 = sub(sub(sqr(R), PPP), dbl(Q));
-    acc.Y = sub(mul(R, sub(Q, X3)), mul(S1, PPP));
+    acc.Y = mul_add2(R, sub(Q, X3), neg(S1), PPP);
     acc.X = X3;
     acc.ZZ = mul(mul(acc.ZZ, q.ZZ), PP);
     acc.ZZZ = mul(mul(acc.ZZZ, q.ZZZ), PPP);

@@ -191,6 +191,19 @@ template <class P> __device__ __forceinline__ Mont<P> mul_comba(const Mont<P> &a
     else { mont_mul_asm_8<P>(r.l, x, y); (void)&mont_mul_holder_8<P>; }
     return r;
 }
+// a*b + c*d with ONE Montgomery reduction (vsp_mm2_12: 432 mads instead of 576).  Sound while p < 2^(32N) / 4 (see the generator).
+template <class P> __device__ __forceinline__ Mont<P> mul2_comba(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) {
+    static_assert(P::N == 12, "dual product is generated for the 12-limb field only");
+    uint32_t x[12], y[12], z[12], w[12];
+    Mont<P> r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { x[i] = a.l[i]; y[i] = b.l[i]; z[i] = c.l[i]; w[i] = d.l[i]; }
+    __builtin_amdgcn_sched_barrier(0);      // this toolchain's machine scheduler crashes (LiveIntervals::handleMove) when it moves
+    mont_mul2_asm_12<P>(r.l, x, y, z, w);   // code across a call that pins 48 operand registers; nothing is lost by fencing it
+    __builtin_amdgcn_sched_barrier(0);
+    (void)&mont_mul2_holder_12<P>;
+    return r;
+}
 #endif
 
 // host: one out-of-line copy per field (the host-side group formulas would otherwise inline dozens of 72-multiply bodies
@@ -206,6 +219,15 @@ template <class P> VSP_HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
 #endif
 }
 template <class P> VSP_HD Mont<P> sqr(const Mont<P> &a) { return mul(a, a); }
+// a*b + c*d: one reduction for the two products on the device's 12-limb field, the plain sum elsewhere
+template <class P> VSP_HD Mont<P> mul_add2(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(typename P::limb_t) == 4 && P::N == 12) return mul2_comba<P>(a, b, c, d);
+    else return add(mul(a, b), mul(c, d));
+#else
+    return add(mul(a, b), mul(c, d));
+#endif
+}
 
 // canonical (plain residue, same limb layout) <-> Montgomery
 template <class P> VSP_HD Mont<P> to_mont(const Mont<P> &canon) { return mul(canon, Mont<P>::r2()); }
@@ -252,6 +274,7 @@ template <class F> VSP_HD Fp2T<F> sqr(const Fp2T<F> &a) {                      /
     F t = mul(a.c0, a.c1);
     Fp2T<F> r; r.c0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1)); r.c1 = dbl(t); return r;
 }
+template <class F> VSP_HD Fp2T<F> mul_add2(const Fp2T<F> &a, const Fp2T<F> &b, const Fp2T<F> &c, const Fp2T<F> &d) { return add(mul(a, b), mul(c, d)); }
 template <class F> VSP_HD Fp2T<F> inv(const Fp2T<F> &a) {
     F n = inv(add(sqr(a.c0), sqr(a.c1)));
     Fp2T<F> r; r.c0 = mul(a.c0, n); r.c1 = neg(mul(a.c1, n)); return r;
@@ -267,5 +290,74 @@ using Fp2 = Fp2T<Fp>;
 using HFp = Mont<FpP64>;
 using HFr = Mont<FrP64>;
 using HFp2 = Fp2T<HFp>;
+
+// ---------------------------------------------------------------- Fp2 split over a lane pair (device only)
+// One Fp2 value lives in two adjacent lanes: the even lane holds c0, the odd lane c1.  Per-lane state is that of an Fp
+// computation, so a kernel over Fp2L runs at the register budget (and occupancy) of the G1 kernels, where one lane holding
+// whole Fp2 values needs > 256 VGPRs and is confined to one wave per SIMD.  Products exchange operands with the partner lane
+// by DPP quad_perm [1,0,3,2]; every lane of a pair must execute the same calls (conditions on Fp2L values are combined over
+// the pair, so data-dependent branches stay pair-uniform).
+struct Fp2L {
+    Fp v;
+    VSP_HD static Fp2L zero() { Fp2L r; r.v = Fp::zero(); return r; }
+#if defined(__HIPCC__)
+    __device__ __forceinline__ static Fp2L one() { Fp2L r; r.v = (threadIdx.x & 1) ? Fp::zero() : Fp::one(); return r; }
+#endif
+};
+#if defined(__HIPCC__)
+// The machine scheduler of this toolchain (clang 22, ROCm 7.2) crashes in LiveIntervals::handleMove when it moves the DPP / select
+// code of the lane-pair products across the fixed-register asm call of the base product; a scheduling fence on either side of
+// each call keeps it from trying (the surrounding code is a few dozen moves, nothing is lost).
+#define VSP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ Fp lane_partner(const Fp &a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < Fp::N; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xF, 0xF, false);
+    return r;
+}
+__device__ __forceinline__ bool pair_all(bool c) {
+    int f = c ? 1 : 0;
+    return (f & __builtin_amdgcn_update_dpp(0, f, 0xB1, 0xF, 0xF, false)) != 0;
+}
+__device__ __forceinline__ Fp lane_select(bool c, const Fp &a, const Fp &b) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < Fp::N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+__device__ __forceinline__ bool is_zero(const Fp2L &a) { return pair_all(is_zero(a.v)); }
+__device__ __forceinline__ Fp2L add(const Fp2L &a, const Fp2L &b) { Fp2L r; r.v = add(a.v, b.v); return r; }
+__device__ __forceinline__ Fp2L sub(const Fp2L &a, const Fp2L &b) { Fp2L r; r.v = sub(a.v, b.v); return r; }
+__device__ __forceinline__ Fp2L neg(const Fp2L &a) { Fp2L r; r.v = neg(a.v); return r; }
+__device__ __forceinline__ Fp2L dbl(const Fp2L &a) { Fp2L r; r.v = dbl(a.v); return r; }
+// (a0 + a1 u)(b0 + b1 u):  even lane a0 b0 - a1 b1,  odd lane a0 b1 + a1 b0  -- two base products per lane
+__device__ __forceinline__ Fp2L mul(const Fp2L &a, const Fp2L &b) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    Fp ap = lane_partner(a.v), bp = lane_partner(b.v);
+    Fp u = lane_select(hi, ap, a.v), w = lane_select(hi, a.v, ap);
+    Fp nb = lane_select(hi, bp, neg(bp));
+    // (the dual-product routine mul_add2(u, b, w, nb) would save a reduction here, but kernels that use it in this place -- and only
+    //  in this place; the G1 formulas use it everywhere -- come out of this toolchain computing wrong sums in k_dimsum's add loop,
+    //  so the two products are reduced separately)
+    VSP_SCHED_FENCE();                               // see VSP_SCHED_FENCE
+    Fp p1 = mul(u, b.v);                             // even: a0 b0      odd: a0 b1
+    VSP_SCHED_FENCE();
+    Fp p2 = mul(w, nb);                              // even: a1 (-b1)   odd: a1 b0
+    VSP_SCHED_FENCE();
+    Fp2L r; r.v = add(p1, p2); return r;
+}
+// (a0 + a1 u)^2:  even lane (a0 + a1)(a0 - a1),  odd lane a0 * 2 a1  -- one base product per lane
+__device__ __forceinline__ Fp2L mul_add2(const Fp2L &a, const Fp2L &b, const Fp2L &c, const Fp2L &d) { return add(mul(a, b), mul(c, d)); }
+__device__ __forceinline__ Fp2L sqr(const Fp2L &a) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    Fp ap = lane_partner(a.v);
+    Fp x = lane_select(hi, ap, add(a.v, ap));        // odd: a0           even: a0 + a1
+    Fp y = lane_select(hi, dbl(a.v), sub(a.v, ap));  // odd: 2 a1         even: a0 - a1
+    VSP_SCHED_FENCE();
+    Fp2L r; r.v = mul(x, y);
+    VSP_SCHED_FENCE();
+    return r;
+}
+#endif
 
 }  // namespace vsp
