@@ -12,10 +12,10 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import vote_saver_protocol_amd as v  # noqa: E402
 
 log_n = int(os.environ.get("LOG_N", "18"))
-pairs = int(os.environ.get("PAIRS", "1"))
 n = 1 << log_n
 ctx = v.Context(0)
-ctx.set_option("msm_g2_lane_pairs", pairs)
+if os.environ.get("WBITS"):
+    ctx.set_option("msm_window_bits", int(os.environ["WBITS"]))
 rng = np.random.default_rng(1)
 ks = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)
 ss = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); ss[:, 3] >>= np.uint64(2)
@@ -28,4 +28,4 @@ bases.msm(d_s)
 t0 = time.perf_counter()
 for _ in range(5):
     r = bases.msm(d_s)
-print("G2 2^%d lane_pairs=%d: %.3f ms per MSM" % (log_n, pairs, (time.perf_counter() - t0) / 5 * 1e3))
+print("G2 2^%d window_bits=%s: %.3f ms per MSM" % (log_n, os.environ.get("WBITS", "auto"), (time.perf_counter() - t0) / 5 * 1e3))
