@@ -213,6 +213,11 @@ int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const
 /* ---- wire format helpers (host only, tiny) --------------------------------------------------- */
 int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]);
 int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]);
+/* Inverse: ZCash-compressed bytes -> canonical affine limbs (the 192-byte proof of bin/cli/src/data.bin[0:192] is A (48) | B (96) |
+ * C (48)).  VSP_ERR_ARG for an encoding that is not compressed form, not canonical (x >= p, stray bits), not on the curve or --
+ * with check_subgroup != 0 -- not in the order-r subgroup. */
+int vsp_g1_decompress(const uint8_t in[48], int check_subgroup, uint64_t out_affine[12], int *out_is_inf);
+int vsp_g2_decompress(const uint8_t in[96], int check_subgroup, uint64_t out_affine[24], int *out_is_inf);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,49 @@ def test_cpp_shims_compile_and_link(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpu_build", "shim_check.cpp"), "-o", exe,
                            "-L", libdir, "-lvsp_hip", "-Wl,-rpath," + libdir])
     assert os.path.exists(exe)
+
+
+def test_wire_format_round_trip_of_reference_proof():
+    """Host-only entry points (no GPU): the library decompresses the reference's data.bin proof (A | B | C) to the points the Python
+    oracle decodes, recompresses them to the same bytes, and rejects malformed encodings."""
+    import bls12_381 as o
+    from conftest import GOLDEN
+    import vote_saver_protocol_amd as v
+    d = bytes.fromhex(open(os.path.join(GOLDEN, "data_bin_proof.hex")).read().strip())
+    A = v.g1_decompress(d[0:48]); B = v.g2_decompress(d[48:144]); Cc = v.g1_decompress(d[144:192])
+    assert o.g1_from_limbs(A) == o.g1_decompress(d[0:48]) and o.g1_from_limbs(Cc) == o.g1_decompress(d[144:192])
+    assert o.g2_from_limbs(B) == o.g2_decompress(d[48:144])
+    assert v.g1_compress(A) + v.g2_compress(B) + v.g1_compress(Cc) == d
+    # both signs of y, infinity, and multiples of the generators
+    for k in (1, 2, 3, 0xdeadbeef, o.R - 1):
+        P1 = o.G1.mul(o.G1.gen, k); P2 = o.G2.mul(o.G2.gen, k)
+        assert o.g1_from_limbs(v.g1_decompress(o.g1_compress(P1))) == P1
+        assert o.g2_from_limbs(v.g2_decompress(o.g2_compress(P2))) == P2
+    assert not v.g1_decompress(o.g1_compress(None)).any() and not v.g2_decompress(o.g2_compress(None)).any()
+    bad = bytearray(d[0:48]); bad[0] &= 0x7f                        # compression flag cleared
+    with pytest.raises(ValueError):
+        v.g1_decompress(bytes(bad))
+    with pytest.raises(ValueError):
+        v.g1_decompress(bytes([0x9f] + [0xff] * 47))                # x >= p
+    # an x with no point on the curve: search a few
+    rejected = 0
+    for x in range(2, 40):
+        enc = bytearray(x.to_bytes(48, "big")); enc[0] |= 0x80
+        try:
+            v.g1_decompress(bytes(enc), check_subgroup=False)
+        except ValueError:
+            rejected += 1
+    assert 5 < rejected < 35                                        # about half of all x have no square root
+    # on the curve but outside the order-r subgroup: accepted without the check, refused with it
+    for x in range(2, 200):
+        enc = bytearray(x.to_bytes(48, "big")); enc[0] |= 0x80
+        try:
+            pt = v.g1_decompress(bytes(enc), check_subgroup=False)
+        except ValueError:
+            continue
+        P = o.g1_from_limbs(pt)
+        assert o.G1.is_on_curve(P)
+        if not o.G1.in_subgroup(P):
+            with pytest.raises(ValueError):
+                v.g1_decompress(bytes(enc), check_subgroup=True)
+            break

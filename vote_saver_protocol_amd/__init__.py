@@ -2,5 +2,5 @@
 reference's multiexp / evaluation_domain / prover call shapes.  See DESIGN.md and include/vsp.h."""
 from ._lib import SO_PATH, VspLibraryMissing, load  # noqa: F401
 from .api import (Bases, Context, EvaluationDomain, Keypair, ProvingKey, R1CS, VspError, fixed_base_mul, fold_jacobian,  # noqa: F401
-                  g1_compress, g2_compress, groth16_prove, make_evaluation_domain, multiexp,
+                  g1_compress, g1_decompress, g2_compress, g2_decompress, groth16_prove, make_evaluation_domain, multiexp,
                   multiexp_with_mixed_addition, witness_map_h)

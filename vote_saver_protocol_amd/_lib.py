@@ -75,6 +75,8 @@ PROTOTYPES = {
     "vsp_selftest_field": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),
     "vsp_g1_compress": (_I, [_P, _P]),
     "vsp_g2_compress": (_I, [_P, _P]),
+    "vsp_g1_decompress": (_I, [_P, _I, _P, _P]),
+    "vsp_g2_decompress": (_I, [_P, _I, _P, _P]),
 }
 
 _lib = None

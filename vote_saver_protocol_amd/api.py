@@ -435,3 +435,21 @@ def g1_compress(affine):
 
 def g2_compress(affine):
     out = np.zeros(96, np.uint8); _lib.load().vsp_g2_compress(_ptr(_u64(affine)), _ptr(out)); return out.tobytes()
+
+
+def g1_decompress(data, check_subgroup=True):
+    """48 ZCash-compressed bytes -> affine limbs [12] (all zero for infinity); ValueError for an invalid encoding."""
+    buf = (C.c_uint8 * 48).from_buffer_copy(bytes(data))
+    out = np.zeros(12, np.uint64); inf = C.c_int(0)
+    if _lib.load().vsp_g1_decompress(buf, int(check_subgroup), _ptr(out), C.byref(inf)) != 0:
+        raise ValueError("g1_decompress: invalid encoding")
+    return out
+
+
+def g2_decompress(data, check_subgroup=True):
+    """96 ZCash-compressed bytes -> affine limbs [24] (all zero for infinity); ValueError for an invalid encoding."""
+    buf = (C.c_uint8 * 96).from_buffer_copy(bytes(data))
+    out = np.zeros(24, np.uint64); inf = C.c_int(0)
+    if _lib.load().vsp_g2_decompress(buf, int(check_subgroup), _ptr(out), C.byref(inf)) != 0:
+        raise ValueError("g2_decompress: invalid encoding")
+    return out

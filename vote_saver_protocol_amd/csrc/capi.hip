@@ -527,4 +527,91 @@ int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]) {
     return VSP_OK;
 }
 
+
+// ---- decompression (the inverse of the above): x from the big-endian bytes, y = sqrt(x^3 + b) with the sign the flag names ----
+static void from_be48(uint64_t *l, const uint8_t *in) {
+    for (int i = 0; i < 6; i++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)in[47 - (i * 8 + b)] << (8 * b); l[i] = v; }
+}
+static bool canon_lt_p(const uint64_t *l) {
+    for (int i = 5; i >= 0; i--) { if (l[i] < FpP64::MOD[i]) return true; if (l[i] > FpP64::MOD[i]) return false; }
+    return false;
+}
+// a^((p+1)/4) -- the square root when a is a quadratic residue (p = 3 mod 4); returns false when it is not
+static bool fp_sqrt(const HFp &a, HFp &out) {
+    uint64_t e[6]; uint64_t carry = 1;                         // e = (p + 1) / 4
+    for (int i = 0; i < 6; i++) { uint64_t v = FpP64::MOD[i] + carry; carry = (v < carry) ? 1 : 0; e[i] = v; }
+    for (int i = 0; i < 6; i++) e[i] = (e[i] >> 2) | (i < 5 ? e[i + 1] << 62 : 0);
+    out = pow_limbs(a, e, 6);
+    return eq(sqr(out), a);
+}
+// square root in Fp2 = Fp[u]/(u^2+1) by the norm: returns false when a is not a square
+static bool fp2_sqrt(const HFp2 &a, HFp2 &out) {
+    if (is_zero(a.c1)) {
+        HFp r;
+        if (fp_sqrt(a.c0, r)) { out.c0 = r; out.c1 = HFp::zero(); return true; }
+        if (fp_sqrt(neg(a.c0), r)) { out.c0 = HFp::zero(); out.c1 = r; return true; }   // (r u)^2 = -r^2
+        return false;
+    }
+    HFp s;
+    if (!fp_sqrt(add(sqr(a.c0), sqr(a.c1)), s)) return false;
+    uint64_t two4[6] = {2, 0, 0, 0, 0, 0};
+    HFp half = inv(host_load_canon<HFp>(two4));
+    HFp t = mul(add(a.c0, s), half), x0;
+    if (!fp_sqrt(t, x0)) { t = mul(sub(a.c0, s), half); if (!fp_sqrt(t, x0)) return false; }
+    out.c0 = x0; out.c1 = mul(mul(a.c1, half), inv(x0));
+    return eq(sqr(out), a);
+}
+static const uint64_t R_LIMBS[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+
+int vsp_g1_decompress(const uint8_t in[48], int check_subgroup, uint64_t out_affine[12], int *out_is_inf) {
+    if (!in || !out_affine) return VSP_ERR_ARG;
+    if (!(in[0] & 0x80)) return VSP_ERR_ARG;                       // uncompressed form is not accepted
+    uint8_t buf[48]; memcpy(buf, in, 48); buf[0] &= 0x1f;
+    if (in[0] & 0x40) {                                            // infinity: every other bit must be clear
+        for (int i = 0; i < 48; i++) if (buf[i]) return VSP_ERR_ARG;
+        if (in[0] & 0x20) return VSP_ERR_ARG;
+        memset(out_affine, 0, 96); if (out_is_inf) *out_is_inf = 1; return VSP_OK;
+    }
+    uint64_t x4[6]; from_be48(x4, buf);
+    if (!canon_lt_p(x4)) return VSP_ERR_ARG;
+    HFp x = host_load_canon<HFp>(x4), y;
+    uint64_t four[6] = {4, 0, 0, 0, 0, 0};
+    if (!fp_sqrt(add(mul(sqr(x), x), host_load_canon<HFp>(four)), y)) return VSP_ERR_ARG;      // not on the curve
+    uint64_t y4[6]; host_store_canon(y4, y);
+    if (fp_lex_larger(y4) != ((in[0] & 0x20) != 0)) { y = neg(y); host_store_canon(y4, y); }
+    if (check_subgroup) {
+        Affine<HFp> p; p.x = x; p.y = y;
+        if (!is_inf(xyzz_mul_scalar(xyzz_from_affine(p), R_LIMBS, 255))) return VSP_ERR_ARG;
+    }
+    memcpy(out_affine, x4, 48); memcpy(out_affine + 6, y4, 48);
+    if (out_is_inf) *out_is_inf = 0;
+    return VSP_OK;
+}
+int vsp_g2_decompress(const uint8_t in[96], int check_subgroup, uint64_t out_affine[24], int *out_is_inf) {
+    if (!in || !out_affine) return VSP_ERR_ARG;
+    if (!(in[0] & 0x80)) return VSP_ERR_ARG;
+    uint8_t buf[96]; memcpy(buf, in, 96); buf[0] &= 0x1f;
+    if (in[0] & 0x40) {
+        for (int i = 0; i < 96; i++) if (buf[i]) return VSP_ERR_ARG;
+        if (in[0] & 0x20) return VSP_ERR_ARG;
+        memset(out_affine, 0, 192); if (out_is_inf) *out_is_inf = 1; return VSP_OK;
+    }
+    uint64_t x1[6], x0[6]; from_be48(x1, buf); from_be48(x0, buf + 48);      // x.c1 first, then x.c0
+    if (!canon_lt_p(x0) || !canon_lt_p(x1)) return VSP_ERR_ARG;
+    HFp2 x, y; x.c0 = host_load_canon<HFp>(x0); x.c1 = host_load_canon<HFp>(x1);
+    uint64_t four[6] = {4, 0, 0, 0, 0, 0};
+    HFp2 b; b.c0 = host_load_canon<HFp>(four); b.c1 = b.c0;                   // 4 (1 + u)
+    if (!fp2_sqrt(add(mul(sqr(x), x), b), y)) return VSP_ERR_ARG;
+    uint64_t y0[6], y1[6]; host_store_canon(y0, y.c0); host_store_canon(y1, y.c1);
+    bool larger = limbs_zero(y1, 6) ? fp_lex_larger(y0) : fp_lex_larger(y1);
+    if (larger != ((in[0] & 0x20) != 0)) { y = neg(y); host_store_canon(y0, y.c0); host_store_canon(y1, y.c1); }
+    if (check_subgroup) {
+        Affine<HFp2> p; p.x = x; p.y = y;
+        if (!is_inf(xyzz_mul_scalar(xyzz_from_affine(p), R_LIMBS, 255))) return VSP_ERR_ARG;
+    }
+    memcpy(out_affine, x0, 48); memcpy(out_affine + 6, x1, 48); memcpy(out_affine + 12, y0, 48); memcpy(out_affine + 18, y1, 48);
+    if (out_is_inf) *out_is_inf = 0;
+    return VSP_OK;
+}
+
 }  // extern "C"
