@@ -10,7 +10,8 @@
 //  * The log2(m) stages are grouped into passes of <= 8 stages.  One workgroup (512 threads) owns a
 //    tile of 2048 elements (64 KiB of LDS, two workgroups per CU), runs all of the pass's stages out
 //    of LDS and touches HBM exactly once for read and once for write: traffic per pass = 64 B/element,
-//    2-4 passes per transform (m = 2^22: 3 passes, 8+7+7 stages).
+//    2-4 passes per transform (m = 2^22: 3 passes, 8+8+6 stages).  Inside a pass the stages run as radix-4 steps: two stages per
+//    LDS round trip and barrier.
 //  * A tile is [2^K butterfly rows] x [C = 2048/2^K contiguous columns]; every global access is a run
 //    of C*32 bytes >= 256 B.  The first pass reads through the bit-reversal permutation (runs of C
 //    inputs) and writes natural order, so no separate permutation pass exists.
@@ -83,23 +84,44 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const Fr *__restrict__
     }
     __syncthreads();
 
-    // ---- K butterfly stages out of LDS
+    // ---- K butterfly stages out of LDS: an odd K starts with one radix-2 stage, the rest run as radix-4 steps (two stages per
+    //      LDS round trip and per barrier; a thread owns the four elements mid0 + {0, h, 2h, 3h} of one column)
     const unsigned lo_part = p.first ? 0u : ((lo_hi << p.clog));
-    for (unsigned t = 0; t < K; t++) {
-        const unsigned s = p.s0 + t;          // global stage: half-size 2^s, twiddle omega_{2^(s+1)}^j
-        const unsigned h = 1u << t;
+    unsigned t = 0;
+    if (K & 1) {
+        const unsigned s = p.s0;              // global stage: half-size 2^s, twiddle omega_{2^(s+1)}^j
         for (unsigned bf = tid; bf < (tile >> 1); bf += NTT_THREADS) {
             unsigned c = bf & (C - 1), q = bf >> p.clog;
-            unsigned mid_lo = q & (h - 1);
-            unsigned mid0 = ((q >> t) << (t + 1)) | mid_lo;
-            unsigned e0 = (mid0 << p.clog) | c, e1 = e0 + (h << p.clog);
+            unsigned e0 = (q << (1 + p.clog)) | c, e1 = e0 + C;
             Fr u = lds_load(pl0, pl1, e0), v = lds_load(pl0, pl1, e1);
-            if (s > 0) {
-                size_t j = ((size_t)mid_lo << p.s0) | (p.first ? 0u : (lo_part | c));
-                v = mul(v, p.tw[j << (p.tlog - 1 - s)]);
-            }
+            if (s > 0) v = mul(v, p.tw[(size_t)(p.first ? 0u : (lo_part | c)) << (p.tlog - 1 - s)]);
             lds_store(pl0, pl1, e0, add(u, v));
             lds_store(pl0, pl1, e1, sub(u, v));
+        }
+        __syncthreads();
+        t = 1;
+    }
+    for (; t < K; t += 2) {
+        const unsigned s = p.s0 + t;          // stages s and s + 1
+        const unsigned h = 1u << t;
+        for (unsigned g = tid; g < (tile >> 2); g += NTT_THREADS) {
+            unsigned c = g & (C - 1), q = g >> p.clog;
+            unsigned mid_lo = q & (h - 1);
+            unsigned mid0 = ((q >> t) << (t + 2)) | mid_lo;
+            unsigned e0 = (mid0 << p.clog) | c, e1 = e0 + (h << p.clog), e2 = e1 + (h << p.clog), e3 = e2 + (h << p.clog);
+            const size_t off = p.first ? 0u : (lo_part | c);
+            Fr x0 = lds_load(pl0, pl1, e0), x1 = lds_load(pl0, pl1, e1), x2 = lds_load(pl0, pl1, e2), x3 = lds_load(pl0, pl1, e3);
+            if (s > 0) {
+                const Fr w1 = p.tw[(((size_t)mid_lo << p.s0) | off) << (p.tlog - 1 - s)];
+                x1 = mul(x1, w1); x3 = mul(x3, w1);
+            }
+            Fr a0 = add(x0, x1), a1 = sub(x0, x1), a2 = add(x2, x3), a3 = sub(x2, x3);
+            a2 = mul(a2, p.tw[(((size_t)mid_lo << p.s0) | off) << (p.tlog - 2 - s)]);
+            a3 = mul(a3, p.tw[(((size_t)(mid_lo + h) << p.s0) | off) << (p.tlog - 2 - s)]);
+            lds_store(pl0, pl1, e0, add(a0, a2));
+            lds_store(pl0, pl1, e1, add(a1, a3));
+            lds_store(pl0, pl1, e2, sub(a0, a2));
+            lds_store(pl0, pl1, e3, sub(a1, a3));
         }
         __syncthreads();
     }
@@ -210,6 +232,11 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
     unsigned npass = log_m <= NTT_TILE_LOG ? 1 : (log_m + NTT_MAX_STAGES - 1) / NTT_MAX_STAGES;
     unsigned stages[8];
     for (unsigned i = 0; i < npass; i++) stages[i] = log_m / npass + (i < log_m % npass ? 1 : 0);
+    // radix-4 steps take stages two at a time: trade a stage between two odd passes (7 + 7 -> 8 + 6), earlier pass the larger
+    for (unsigned i = 0; i + 1 < npass; i++)
+        if (stages[i] & 1)
+            for (unsigned k = i + 1; k < npass; k++)
+                if ((stages[k] & 1) && stages[i] < NTT_MAX_STAGES && stages[k] > 1) { stages[i]++; stages[k]--; break; }
 
     Fr *scratch = nullptr;
     if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * sizeof(Fr))); scratch = (Fr *)ctx->ntt_scratch.p; }
