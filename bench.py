@@ -421,16 +421,16 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
-                     "note": "integer-VALU bound (about 150 Montgomery products per point), not HBM bound; launch time is measured while the "
+                     "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
                              "neighbouring step's kernels share the GPU (two-deep pipeline); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
                              "profiles/r1_c_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
-        # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 8 single products (288 limb
-        # products each: 144 for the product, 144 for the reduction) + 1 dual product a*b + c*d with one reduction (432) = 2736; peak = measured v_mad_u64_u32 issue rate (profiles/r1_ubench_valu.txt:
+        # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products
+        # = 10 * 2*12*12 limb products; peak = measured v_mad_u64_u32 issue rate (profiles/r1_ubench_valu.txt:
         # 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same k_accum launch time as above.
         "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum (bucket accumulation)",
-                          "achieved": n * main_w * 2736 / accum_avg_s / 1e12 if accum_launches else None,
+                          "achieved": n * main_w * 2880 / accum_avg_s / 1e12 if accum_launches else None,
                           "peak": 1.46e9 * 64 * 256 / 1e12, "unit": "T limb-products/s",
-                          "frac": (n * main_w * 2736 / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},
+                          "frac": (n * main_w * 2880 / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},
         "cpu_baseline": cpu_baseline,
     }
     if extras:

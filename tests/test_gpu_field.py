@@ -48,9 +48,3 @@ def test_field_golden_and_random(ctx, field, mod, nl, key):
     assert ints(run(ctx, field, 4, a, b), nl) == [x * y % mod for x, y in zip(A, B)]
     n_inv = 300
     assert ints(run(ctx, field, 5, a[:n_inv], b[:n_inv]), nl) == [pow(x, mod - 2, mod) for x in A[:n_inv]]
-    # a*b + c*d with one reduction (Fp: the dual-product routine; Fr: the plain sum)
-    assert ints(run(ctx, field, 6, a, b), nl) == [(x * y + (x + y) * (x - y)) % mod for x, y in zip(A, B)]
-    # raw operands, including x = y = p - 1 where a*b + c*d is largest: (x^2 + y^2) / R
-    A2 = A + [mod - 1, mod - 1, mod - 2, 0]; B2 = B + [mod - 1, mod - 2, mod - 1, mod - 1]
-    rinv = pow(1 << (64 * nl), mod - 2, mod)
-    assert ints(run(ctx, field, 7, limbs_arr(A2, nl), limbs_arr(B2, nl)), nl) == [(x * x + y * y) * rinv % mod for x, y in zip(A2, B2)]

@@ -25,18 +25,13 @@ import os
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vote_saver_protocol_amd", "csrc", "mont_asm_gfx950.h")
 
 
-def body(N, dual=False):
-    """dual: r = (a*b + c*d) * 2^(-32N) mod p with ONE reduction -- the two products share the column accumulators.
-    Needs a*b + c*d + m*p < 2p * 2^(32N), true for fully reduced inputs when p < 2^(32N) / 4 (BLS12-381: p = 0.10 * 2^384)."""
+def body(N):
     A = lambda i: f"v{i}"
     B = lambda i: f"v{N + i}"
-    Cc = lambda i: f"v{2 * N + i}"
-    D = lambda i: f"v{3 * N + i}"
-    nin = 4 if dual else 2
-    M = lambda i: f"v{nin * N + i}"
+    M = lambda i: f"v{2 * N + i}"
     Pm = lambda i: f"s{i}"
     INV = "s12"
-    base = (nin + 1) * N
+    base = 3 * N
     pairs = [(f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]"), (f"v{base + 2}", f"v{base + 3}", f"v[{base + 2}:{base + 3}]")]
     ins = []
     cur, oth = 0, 1
@@ -49,18 +44,12 @@ def body(N, dual=False):
         if k < N:
             for i in range(k):
                 terms.append((A(i), B(k - i)))
-                if dual:
-                    terms.append((Cc(i), D(k - i)))
                 terms.append((M(i), Pm(k - i)))
             terms.append((A(k), B(0)))
-            if dual:
-                terms.append((Cc(k), D(0)))
             terms.append(("MK", None))
         else:
             for i in range(k - N + 1, N):
                 terms.append((A(i), B(k - i)))
-                if dual:
-                    terms.append((Cc(i), D(k - i)))
                 terms.append((M(i), Pm(k - i)))
         first = True
         for x, y in terms:
@@ -88,23 +77,20 @@ def body(N, dual=False):
     return ins
 
 
-def gen(N, dual=False):
-    ins = body(N, dual)
+def gen(N):
+    ins = body(N)
     n_mad = sum(1 for x in ins if x.startswith("v_mad"))
-    tag = "mm2" if dual else "mm"
-    nin = 4 if dual else 2
-    label = f"vsp_{tag}_{N}"
-    lines = [f's_branch .Lvsp_{tag}_{N}_end', '.p2align 8', f'{label}:']
+    label = f"vsp_mm_{N}"
+    lines = [f's_branch .Lvsp_mm_{N}_end', '.p2align 8', f'{label}:']
     lines += [f's_mov_b32 s{i}, %[p{i}]' for i in range(N)]      # literal constants via "i" operands
     lines += ['s_mov_b32 s12, %[inv]']
-    lines += ins + ['s_setpc_b64 s[30:31]', f'.Lvsp_{tag}_{N}_end:']
+    lines += ins + ['s_setpc_b64 s[30:31]', f'.Lvsp_mm_{N}_end:']
     body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
     consts = ", ".join([f'[p{i}] "i"(P::MOD[{i}])' for i in range(N)] + ['[inv] "i"(P::INV)'])
-    vclob = ", ".join(f'"v{i}"' for i in range((nin + 1) * N + 4))
+    vclob = ", ".join(f'"v{i}"' for i in range(3 * N + 4))
     sclob = ", ".join(f'"s{i}"' for i in range(13))
-    fn = "mont_mul2" if dual else "mont_mul"
-    holder = f'''// ---- N = {N}{" (a*b + c*d, one reduction)" if dual else ""}: {n_mad} v_mad_u64_u32, {len(ins)} instructions, VGPRs v0..v{(nin + 1) * N + 3} ----
-template <class P> __device__ __attribute__((noinline, used)) void {fn}_holder_{N}() {{
+    holder = f'''// ---- N = {N}: {n_mad} v_mad_u64_u32, {len(ins)} instructions, VGPRs v0..v{3 * N + 3} ----
+template <class P> __device__ __attribute__((noinline, used)) void mont_mul_holder_{N}() {{
     static_assert(P::N == {N}, "limb count");
     asm volatile(
 {body_txt}
@@ -113,14 +99,11 @@ template <class P> __device__ __attribute__((noinline, used)) void {fn}_holder_{
         : "vcc", "scc", "s30", "s31", {sclob}, {vclob});
 }}
 '''
-    outs = ", ".join([f'"={{v{nin * N + i}}}"(r[{i}])' for i in range(N)] + [f'"+{{v{i}}}"(a[{i}])' for i in range(N)] +
-                     [f'"+{{v{N + i}}}"(b[{i}])' for i in range(N)] +
-                     ([f'"+{{v{2 * N + i}}}"(c[{i}])' for i in range(N)] + [f'"+{{v{3 * N + i}}}"(d[{i}])' for i in range(N)] if dual else []))
-    acc = ", ".join(f'"v{(nin + 1) * N + i}"' for i in range(4))
-    what = f"(a*b + c*d)*2^(-{32 * N})" if dual else f"a*b*2^(-{32 * N})"
-    args = "uint32_t *r, uint32_t *a, uint32_t *b, uint32_t *c, uint32_t *d" if dual else "uint32_t *r, uint32_t *a, uint32_t *b"
-    call = f'''// r = {what} mod p, fully reduced.  The operand arrays are clobbered.
-template <class P> __device__ __forceinline__ void {fn}_asm_{N}({args}) {{
+    outs = ", ".join([f'"={{v{2 * N + i}}}"(r[{i}])' for i in range(N)] + [f'"+{{v{i}}}"(a[{i}])' for i in range(N)] +
+                     [f'"+{{v{N + i}}}"(b[{i}])' for i in range(N)])
+    acc = ", ".join(f'"v{3 * N + i}"' for i in range(4))
+    call = f'''// r = a*b*2^(-{32 * N}) mod p, fully reduced.  a[] and b[] are clobbered.
+template <class P> __device__ __forceinline__ void mont_mul_asm_{N}(uint32_t *r, uint32_t *a, uint32_t *b) {{
     asm("s_getpc_b64 s[30:31]\\n\\t"
         "s_add_u32 s30, s30, {label}@rel32@lo+4\\n\\t"
         "s_addc_u32 s31, s31, {label}@rel32@hi+12\\n\\t"
@@ -140,7 +123,7 @@ def main():
 
 namespace vsp {
 
-''' + gen(12) + "\n" + gen(8) + "\n" + gen(12, dual=True) + "\n}  // namespace vsp\n"
+''' + gen(12) + "\n" + gen(8) + "\n}  // namespace vsp\n"
     open(OUT, "w").write(text)
     print("wrote", os.path.normpath(OUT))
 

@@ -61,9 +61,7 @@ template <class F> __global__ __launch_bounds__(64) void k_selftest_field(int op
         case 2: r = sub(x, y); break;
         case 3: r = from_mont(sqr(to_mont(x))); break;
         case 4: r = mul(x, to_mont(y)); break;          // canonical x Montgomery -> canonical (the NTT butterfly product)
-        case 5: r = from_mont(inv(to_mont(x))); break;
-        case 6: r = from_mont(mul_add2(to_mont(x), to_mont(y), to_mont(add(x, y)), to_mont(sub(x, y)))); break;   // xy + (x+y)(x-y)
-        default: r = mul_add2(x, x, y, y); break;       // raw operands: (x^2 + y^2) / R, exercises the reduction bound at x = y = p-1
+        default: r = from_mont(inv(to_mont(x))); break;
     }
     out[i] = r;
 }
@@ -76,7 +74,7 @@ extern "C" {
 
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     if (!ctx) return VSP_ERR_ARG;
-    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 7) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
+    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 5) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
     VSP_HIP(hipSetDevice(ctx->device));
     size_t esz = field == 0 ? sizeof(Fp) : sizeof(Fr);
     DevBuf da, db, dc;

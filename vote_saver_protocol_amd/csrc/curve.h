@@ -36,15 +36,14 @@ template <class F> VSP_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
     if (is_inf(p)) return p;
     F U = dbl(p.Y);
     F V = sqr(U);
-    F W = mul(U, V);
-    F S = mul(p.X, V);
+    F W, S;
+    mul_pair(U, V, p.X, V, W, S);
     F XX = sqr(p.X);
     F M = add(dbl(XX), XX);
     XYZZ<F> r;
     r.X = sub(sqr(M), dbl(S));
-    r.Y = mul_add2(M, sub(S, r.X), neg(W), p.Y);
-    r.ZZ = mul(V, p.ZZ);
-    r.ZZZ = mul(W, p.ZZZ);
+    r.Y = prod_diff(M, sub(S, r.X), W, p.Y);
+    mul_pair(V, p.ZZ, W, p.ZZZ, r.ZZ, r.ZZZ);
     return r;       // Y = 0 cannot occur: the groups have odd order
 }
 
@@ -52,13 +51,13 @@ template <class F> VSP_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
 template <class F> VSP_HD XYZZ<F> xyzz_dbl_affine(const Affine<F> &p) {
     F U = dbl(p.y);
     F V = sqr(U);
-    F W = mul(U, V);
-    F S = mul(p.x, V);
+    F W, S;
+    mul_pair(U, V, p.x, V, W, S);
     F XX = sqr(p.x);
     F M = add(dbl(XX), XX);
     XYZZ<F> r;
     r.X = sub(sqr(M), dbl(S));
-    r.Y = mul_add2(M, sub(S, r.X), neg(W), p.y);
+    r.Y = prod_diff(M, sub(S, r.X), W, p.y);
     r.ZZ = V;
     r.ZZZ = W;
     return r;
@@ -70,8 +69,8 @@ template <class F> VSP_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bo
     Affine<F> q = q_in;
     if (negate) q.y = neg(q.y);
     if (is_inf(acc)) { acc.X = q.x; acc.Y = q.y; acc.ZZ = F::one(); acc.ZZZ = F::one(); return; }
-    F U2 = mul(q.x, acc.ZZ);
-    F S2 = mul(q.y, acc.ZZZ);
+    F U2, S2;
+    mul_pair(q.x, acc.ZZ, q.y, acc.ZZZ, U2, S2);
     F P = sub(U2, acc.X);
     F R = sub(S2, acc.Y);
     if (is_zero(P)) {
@@ -80,23 +79,21 @@ template <class F> VSP_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q_in, bo
         return;
     }
     F PP = sqr(P);
-    F PPP = mul(P, PP);
-    F Q = mul(acc.X, PP);
+    F PPP, Q;
+    mul_pair(P, PP, acc.X, PP, PPP, Q);
     F X3 = sub(sub(sqr(R), PPP), dbl(Q));
-    acc.Y = mul_add2(R, sub(Q, X3), neg(acc.Y), PPP);        // R (Q - X3) - Y1 PPP, one reduction
+    acc.Y = prod_diff(R, sub(Q, X3), acc.Y, PPP);            // R (Q - X3) - Y1 PPP
     acc.X = X3;
-    acc.ZZ = mul(acc.ZZ, PP);
-    acc.ZZZ = mul(acc.ZZZ, PPP);
+    mul_pair(acc.ZZ, PP, acc.ZZZ, PPP, acc.ZZ, acc.ZZZ);
 }
 
 // acc += q (both XYZZ)
 template <class F> VSP_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
     if (is_inf(q)) return;
     if (is_inf(acc)) { acc = q; return; }
-    F U1 = mul(acc.X, q.ZZ);
-    F U2 = mul(q.X, acc.ZZ);
-    F S1 = mul(acc.Y, q.ZZZ);
-    F S2 = mul(q.Y, acc.ZZZ);
+    F U1, U2, S1, S2;
+    mul_pair(acc.X, q.ZZ, q.X, acc.ZZ, U1, U2);
+    mul_pair(acc.Y, q.ZZZ, q.Y, acc.ZZZ, S1, S2);
     F P = sub(U2, U1);
     F R = sub(S2, S1);
     if (is_zero(P)) {
@@ -105,13 +102,14 @@ template <class F> VSP_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
         return;
     }
     F PP = sqr(P);
-    F PPP = mul(P, PP);
-    F Q = mul(U1, PP);
+    F PPP, Q;
+    mul_pair(P, PP, U1, PP, PPP, Q);
     F X3 = sub(sub(sqr(R), PPP), dbl(Q));
-    acc.Y = mul_add2(R, sub(Q, X3), neg(S1), PPP);
+    acc.Y = prod_diff(R, sub(Q, X3), S1, PPP);
     acc.X = X3;
-    acc.ZZ = mul(mul(acc.ZZ, q.ZZ), PP);
-    acc.ZZZ = mul(mul(acc.ZZZ, q.ZZZ), PPP);
+    F zz, zzz;
+    mul_pair(acc.ZZ, q.ZZ, acc.ZZZ, q.ZZZ, zz, zzz);
+    mul_pair(zz, PP, zzz, PPP, acc.ZZ, acc.ZZZ);
 }
 
 template <class F> VSP_HD XYZZ<F> xyzz_neg(const XYZZ<F> &p) { XYZZ<F> r = p; r.Y = neg(p.Y); return r; }

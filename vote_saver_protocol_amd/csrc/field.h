@@ -191,19 +191,6 @@ template <class P> __device__ __forceinline__ Mont<P> mul_comba(const Mont<P> &a
     else { mont_mul_asm_8<P>(r.l, x, y); (void)&mont_mul_holder_8<P>; }
     return r;
 }
-// a*b + c*d with ONE Montgomery reduction (vsp_mm2_12: 432 mads instead of 576).  Sound while p < 2^(32N) / 4 (see the generator).
-template <class P> __device__ __forceinline__ Mont<P> mul2_comba(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) {
-    static_assert(P::N == 12, "dual product is generated for the 12-limb field only");
-    uint32_t x[12], y[12], z[12], w[12];
-    Mont<P> r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) { x[i] = a.l[i]; y[i] = b.l[i]; z[i] = c.l[i]; w[i] = d.l[i]; }
-    __builtin_amdgcn_sched_barrier(0);      // this toolchain's machine scheduler crashes (LiveIntervals::handleMove) when it moves
-    mont_mul2_asm_12<P>(r.l, x, y, z, w);   // code across a call that pins 48 operand registers; nothing is lost by fencing it
-    __builtin_amdgcn_sched_barrier(0);
-    (void)&mont_mul2_holder_12<P>;
-    return r;
-}
 #endif
 
 // host: one out-of-line copy per field (the host-side group formulas would otherwise inline dozens of 72-multiply bodies
@@ -219,15 +206,11 @@ template <class P> VSP_HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
 #endif
 }
 template <class P> VSP_HD Mont<P> sqr(const Mont<P> &a) { return mul(a, a); }
-// a*b + c*d: one reduction for the two products on the device's 12-limb field, the plain sum elsewhere
-template <class P> VSP_HD Mont<P> mul_add2(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (sizeof(typename P::limb_t) == 4 && P::N == 12) return mul2_comba<P>(a, b, c, d);
-    else return add(mul(a, b), mul(c, d));
-#else
-    return add(mul(a, b), mul(c, d));
-#endif
-}
+// a*b + c*d.  (A dual-product routine -- both products into one set of column accumulators, one reduction, 432 limb products
+// instead of 576 -- was built and measured in round 1: +4 % on the G1 accumulation.  It passed its field tests, but kernels using it
+// computed wrong bucket sums in some code arrangements and not in others (same source, same inputs; neither tied operands, spills,
+// scheduling nor volatility of the asm explained it), so it is not used: a prover must not depend on which arrangement compiles right.)
+template <class P> VSP_HD Mont<P> mul_add2(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) { return add(mul(a, b), mul(c, d)); }
 
 // canonical (plain residue, same limb layout) <-> Montgomery
 template <class P> VSP_HD Mont<P> to_mont(const Mont<P> &canon) { return mul(canon, Mont<P>::r2()); }
@@ -275,6 +258,12 @@ template <class F> VSP_HD Fp2T<F> sqr(const Fp2T<F> &a) {                      /
     Fp2T<F> r; r.c0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1)); r.c1 = dbl(t); return r;
 }
 template <class F> VSP_HD Fp2T<F> mul_add2(const Fp2T<F> &a, const Fp2T<F> &b, const Fp2T<F> &c, const Fp2T<F> &d) { return add(mul(a, b), mul(c, d)); }
+// The group formulas ask for their products through two helpers so that each field can batch them its own way:
+//   mul_pair(a, b, c, d, p, q): p = a*b, q = c*d (independent products)        prod_diff(a, b, c, d) = a*b - c*d
+template <class P> VSP_HD void mul_pair(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d, Mont<P> &p, Mont<P> &q) { p = mul(a, b); q = mul(c, d); }
+template <class P> VSP_HD Mont<P> prod_diff(const Mont<P> &a, const Mont<P> &b, const Mont<P> &c, const Mont<P> &d) { return sub(mul(a, b), mul(c, d)); }
+template <class F> VSP_HD void mul_pair(const Fp2T<F> &a, const Fp2T<F> &b, const Fp2T<F> &c, const Fp2T<F> &d, Fp2T<F> &p, Fp2T<F> &q) { p = mul(a, b); q = mul(c, d); }
+template <class F> VSP_HD Fp2T<F> prod_diff(const Fp2T<F> &a, const Fp2T<F> &b, const Fp2T<F> &c, const Fp2T<F> &d) { return sub(mul(a, b), mul(c, d)); }
 template <class F> VSP_HD Fp2T<F> inv(const Fp2T<F> &a) {
     F n = inv(add(sqr(a.c0), sqr(a.c1)));
     Fp2T<F> r; r.c0 = mul(a.c0, n); r.c1 = neg(mul(a.c1, n)); return r;
@@ -336,9 +325,6 @@ __device__ __forceinline__ Fp2L mul(const Fp2L &a, const Fp2L &b) {
     Fp ap = lane_partner(a.v), bp = lane_partner(b.v);
     Fp u = lane_select(hi, ap, a.v), w = lane_select(hi, a.v, ap);
     Fp nb = lane_select(hi, bp, neg(bp));
-    // (the dual-product routine mul_add2(u, b, w, nb) would save a reduction here, but kernels that use it in this place -- and only
-    //  in this place; the G1 formulas use it everywhere -- come out of this toolchain computing wrong sums in k_dimsum's add loop,
-    //  so the two products are reduced separately)
     VSP_SCHED_FENCE();                               // see VSP_SCHED_FENCE
     Fp p1 = mul(u, b.v);                             // even: a0 b0      odd: a0 b1
     VSP_SCHED_FENCE();
@@ -347,7 +333,30 @@ __device__ __forceinline__ Fp2L mul(const Fp2L &a, const Fp2L &b) {
     Fp2L r; r.v = add(p1, p2); return r;
 }
 // (a0 + a1 u)^2:  even lane (a0 + a1)(a0 - a1),  odd lane a0 * 2 a1  -- one base product per lane
-__device__ __forceinline__ Fp2L mul_add2(const Fp2L &a, const Fp2L &b, const Fp2L &c, const Fp2L &d) { return add(mul(a, b), mul(c, d)); }
+// Two independent products p = a*b, q = c*d over the lane pair by Karatsuba: SIX base products for the two (three per lane) instead
+// of eight.  Even lane: a0 b0, c0 d0, (a0 + a1)(b0 + b1); odd lane: a1 b1, c1 d1, (c0 + c1)(d0 + d1); then one exchange round:
+//   p0 = a0 b0 - a1 b1      p1 = [(a0 + a1)(b0 + b1) - a0 b0] - a1 b1      q0 = c0 d0 - c1 d1      q1 = [(c0 + c1)(d0 + d1) - c1 d1] - c0 d0
+__device__ __forceinline__ void mul_pair(const Fp2L &a, const Fp2L &b, const Fp2L &c, const Fp2L &d, Fp2L &p, Fp2L &q) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    // the operand pair whose cross sum this lane forms: even (a, b), odd (c, d)
+    Fp x = lane_select(hi, c.v, a.v), y = lane_select(hi, d.v, b.v);
+    Fp xs = lane_select(hi, a.v, c.v), ys = lane_select(hi, b.v, d.v);      // what the partner needs from this lane
+    Fp s1 = add(x, lane_partner(xs)), s2 = add(y, lane_partner(ys));         // even: a0 + a1, b0 + b1      odd: c1 + c0, d1 + d0
+    VSP_SCHED_FENCE();
+    Fp m1 = mul(a.v, b.v);                                                   // even: a0 b0    odd: a1 b1
+    VSP_SCHED_FENCE();
+    Fp m2 = mul(c.v, d.v);                                                   // even: c0 d0    odd: c1 d1
+    VSP_SCHED_FENCE();
+    Fp m3 = mul(s1, s2);
+    VSP_SCHED_FENCE();
+    Fp t = sub(m3, lane_select(hi, m2, m1));                                 // even: (a0+a1)(b0+b1) - a0 b0     odd: (c0+c1)(d0+d1) - c1 d1
+    Fp m2r = lane_partner(m2);                                               // even: c1 d1    odd: c0 d0
+    Fp yr = lane_partner(lane_select(hi, m1, t));                            // even receives a1 b1, odd receives the even lane's t
+    p.v = sub(lane_select(hi, yr, m1), lane_select(hi, m1, yr));             // even: a0 b0 - a1 b1     odd: t_even - a1 b1
+    q.v = sub(lane_select(hi, t, m2), m2r);                                  // even: c0 d0 - c1 d1     odd: t_odd - c0 d0
+}
+__device__ __forceinline__ Fp2L prod_diff(const Fp2L &a, const Fp2L &b, const Fp2L &c, const Fp2L &d) { Fp2L p, q; mul_pair(a, b, c, d, p, q); return sub(p, q); }
+__device__ __forceinline__ Fp2L mul_add2(const Fp2L &a, const Fp2L &b, const Fp2L &c, const Fp2L &d) { Fp2L p, q; mul_pair(a, b, c, d, p, q); return add(p, q); }
 __device__ __forceinline__ Fp2L sqr(const Fp2L &a) {
     const bool hi = (threadIdx.x & 1) != 0;
     Fp ap = lane_partner(a.v);
