@@ -39,6 +39,24 @@ def test_status_codes_and_messages(ctx, cref):
     rp = np.array([0, 1], np.uint32); ci = np.array([7], np.uint32); co = np.array([[1, 0, 0, 0]], np.uint64)
     assert not lib.vsp_r1cs_upload(ctx.h, 1, 0, 2, p(rp), p(ci), p(co), p(rp), p(ci), p(co), p(rp), p(ci), p(co))
     assert "column" in ctx.last_error()
+    # evaluation-domain handles
+    assert not lib.vsp_domain_create(ctx.h, 1) and "min_size" in ctx.last_error()          # a domain has at least two elements
+    assert not lib.vsp_domain_create(ctx.h, (1 << 28) + 1)                                   # larger than 2^28
+    assert lib.vsp_domain_size(NULL) == 0 and lib.vsp_domain_kind(NULL) == -1
+    dom = lib.vsp_domain_create(ctx.h, 12)
+    assert dom and lib.vsp_domain_size(dom) == 12 and lib.vsp_domain_kind(dom) == 1
+    assert lib.vsp_domain_fft(ctx.h, dom, NULL, 0, NULL) == -1
+    assert lib.vsp_domain_fft(ctx.h, NULL, p(a), 0, NULL) == -1
+    a12 = rand_fr_array(12, 4)
+    assert lib.vsp_domain_fft(ctx.h, dom, p(a12), 0, p(zero_g)) == -1                        # coset generator 0
+    o4 = np.zeros(4, np.uint64)
+    assert lib.vsp_domain_element(ctx.h, dom, 12, p(o4)) == -1                               # index out of range
+    assert lib.vsp_domain_lagrange(ctx.h, dom, NULL, p(a12)) == -1
+    assert lib.vsp_domain_witness_map_h(ctx.h, dom, p(a12), p(a12), NULL, p(a12)) == -1
+    lib.vsp_domain_free(ctx.h, dom); lib.vsp_domain_free(ctx.h, NULL)
+    # wire format: malformed encodings are refused with a status, not decoded
+    enc = (C.c_uint8 * 48)(*([0x1f] + [0] * 47))                                              # compression flag missing
+    assert lib.vsp_g1_decompress(enc, 1, p(out), C.byref(inf)) == -1
     # the context still works afterwards
     b = cref.g1_batch_mul_gen(rand_fr_array(10, 2)); s = rand_fr_array(10, 3)
     assert np.array_equal(v.multiexp(ctx, b, s, 1), cref.msm_g1(b, s))
