@@ -388,11 +388,11 @@ def main():
     accum_avg_s = (accum_ms / accum_launches) * 1e-3 if accum_launches else float("nan")
     achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
     # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
-    # from the committed summary of the same command, profiles/r1_c_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
+    # from the committed summary of the same command, profiles/r1_g_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
     try:
         if args.log_n == 20:
-            with open(os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1_g_pmc_hbm_traffic.json")) as f:
                 traffic = json.load(f)["k_accum_G1_2p20"]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -423,7 +423,7 @@ def main():
                      "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
                      "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
                              "neighbouring step's kernels share the GPU (two-deep pipeline); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
-                             "profiles/r1_c_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
+                             "profiles/r1_g_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
         # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products
         # = 10 * 2*12*12 limb products; peak = measured v_mad_u64_u32 issue rate (profiles/r1_ubench_valu.txt:
         # 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same k_accum launch time as above.
