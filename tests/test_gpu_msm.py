@@ -167,6 +167,31 @@ def test_msm_full_size_2p20_discrete_log_identity(ctx, cref):
         B.free(); ctx.dfree(d_b); ctx.dfree(d_k); ctx.dfree(d_s)
 
 
+@pytest.mark.parametrize("precompute", [False, True])
+def test_msm_g2_2p18_discrete_log_identity(ctx, cref, precompute):
+    """G2 at a size that fills the GPU (the lane-pair kernels with every part count, merges, the three-digit bucket reduction),
+    plain bases and precomputed window multiples: sum s_i (k_i G2) = (sum k_i s_i) G2, and a slice bit for bit vs the C oracle."""
+    n = 1 << 18
+    ks = rand_fr_array(n, seed=31)
+    ss = rand_fr_array(n, seed=32)
+    ss[:20000] = 0; ss[:10000, 0] = 1                      # zeros and ones among the scalars (multiexp_with_mixed_addition's cases)
+    d_k = ctx.to_device(ks); d_s = ctx.to_device(ss)
+    d_b = v.fixed_base_mul(ctx, d_k, n, 2)
+    B = ctx.bases_from_device(d_b, n, 2)
+    if precompute:
+        B.precompute(0)
+    try:
+        got, inf = B.msm(d_s)
+        e = sum(a * b for a, b in zip(fr_ints_fast(ks), fr_ints_fast(ss))) % o.R
+        assert not inf and np.array_equal(got, cref.g2_mul(g2_limbs(o.G2.gen), L(e, 4)))
+        m = 1 << 13
+        host_b = np.zeros((m, 24), np.uint64); ctx.d2h(host_b, d_b + 192 * 5555)
+        part, _ = B.msm(d_s + 32 * 5555, n=m, first=5555)
+        assert np.array_equal(part, cref.msm_g2(host_b, ss[5555:5555 + m], mixed=True))
+    finally:
+        B.free(); ctx.dfree(d_b); ctx.dfree(d_k); ctx.dfree(d_s)
+
+
 def test_msm_pipelined_slots_and_shared_streams(ctx, cref):
     """vsp_msm_launch / vsp_msm_finish_jacobian: several multi-exponentiations in flight on their own streams (G1 and G2
     mixed), finished out of order; results identical to the blocking calls and to the oracle."""

@@ -65,6 +65,38 @@ def test_gpu_proof_satisfies_pairing_equation(ctx, cref):
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
 
 
+def test_generate_and_prove_2p16_step_domain_pairing(ctx, cref):
+    """End to end at a size that takes the production paths (LDS counting sort, precomputed key with a shared bucket plan, the
+    all-ones bucket split over hundreds of parts, a step radix-2 domain of 2^16 + 2^13 elements): key generated on the GPU, proof
+    made on the GPU, Groth16 pairing equation checked by the oracle's pairing."""
+    import pairing as pg
+    ni = 6
+    nc = (1 << 16) + (1 << 13) - ni - 40
+    gen = o.splitmix64(123)
+    cs, wit = cref.R1CS.synth(nc, ni, 21)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    A, B, Cm = cs.export()
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, A, B, Cm)
+    assert dcs.m == (1 << 16) + (1 << 13) and dcs.domain_kind == "step_radix2"
+    kp = v.Keypair(ctx, dcs, tox, precompute=True)
+    r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
+    pa, pb, pc, proof = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
+    vk = dict(alpha_g1=o.g1_from_limbs(kp.part("alpha_g1")[0]), beta_g2=o.g2_from_limbs(kp.part("beta_g2")[0]),
+              gamma_g2=o.g2_from_limbs(kp.part("gamma_g2")[0]), delta_g2=o.g2_from_limbs(kp.part("delta_g2")[0]),
+              gamma_ABC_g1=[o.g1_from_limbs(x) for x in kp.part("gamma_ABC_g1")])
+    pub = [I(wit[i]) for i in range(ni)]
+    assert pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
+    # the 192 proof bytes decode back to the same points
+    assert np.array_equal(v.g1_decompress(proof[0:48]), pa) and np.array_equal(v.g2_decompress(proof[48:144]), pb)
+    assert np.array_equal(v.g1_decompress(proof[144:192]), pc)
+    # a second proof with other randomness verifies too and differs
+    r2 = L(o.rand_fr(gen), 4)
+    qa, qb, qc, _ = v.groth16_prove(ctx, dcs, kp.pk, wit, r2, s)
+    assert not np.array_equal(qa, pa)
+    assert pg.groth16_verify(vk, pub, (o.g1_from_limbs(qa), o.g2_from_limbs(qb), o.g1_from_limbs(qc)))
+    kp.free(); dcs.free(); cs.free()
+
+
 def test_prove_rejects_mismatched_key(ctx, cref):
     cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, 40, 2, seed=3)
     cs2, wit2 = cref.R1CS.synth(41, 2, 3)
