@@ -84,7 +84,9 @@ def gen(N):
     lines = [f's_branch .Lvsp_mm_{N}_end', '.p2align 8', f'{label}:']
     lines += [f's_mov_b32 s{i}, %[p{i}]' for i in range(N)]      # literal constants via "i" operands
     lines += ['s_mov_b32 s12, %[inv]']
-    lines += ins + ['s_setpc_b64 s[30:31]', f'.Lvsp_mm_{N}_end:']
+    # the compiler's hazard recogniser does not see inside inline asm: a DPP (or readlane) read of a result register needs >= 2 wait
+    # states after the v_cndmask that wrote it, and the lane-pair Fp2 code does follow products with DPP moves -- pad before returning
+    lines += ins + ['s_nop 4', 's_setpc_b64 s[30:31]', f'.Lvsp_mm_{N}_end:']
     body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
     consts = ", ".join([f'[p{i}] "i"(P::MOD[{i}])' for i in range(N)] + ['[inv] "i"(P::INV)'])
     vclob = ", ".join(f'"v{i}"' for i in range(3 * N + 4))
