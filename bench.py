@@ -341,6 +341,13 @@ def main():
             extras["ntt_2p22_ms"] = dtn * 1e3
             extras["ntt_2p22_elements_per_s"] = (1 << lg) / dtn
             extras["ntt_2p22_algorithmic_GBs"] = (1 << lg) * 64 / dtn / 1e9
+            # algorithmic bytes = 64 B per element for the whole transform (one ideal read + write); the kernel makes
+            # `passes` round trips through HBM, each reading and writing every element once
+            npass = int(ctx.stat("ntt_passes"))
+            extras["roofline_ntt_2p22"] = {"bound": "hbm", "kernel": "k_ntt_pass (all passes of one transform)", "achieved": (1 << lg) * 64 / dtn / 1e9,
+                                           "peak": 8000.0, "unit": "GB/s", "frac": (1 << lg) * 64 / dtn / 1e9 / 8000.0, "passes": npass,
+                                           "actual_bytes_moved": npass * (1 << lg) * 64, "per_pass_GBs": (1 << lg) * 64 / (dtn / npass) / 1e9,
+                                           "note": "integer-VALU bound: 11 Fr products per element; see DESIGN.md 3.2 for the measured split"}
             del a
             # G2: 2^18 points, and 2^21 = the per-GPU shard of BASELINE config 5 (2^24 G2 points over 8 GPUs); verified through the
             # discrete-log identity sum_i s_i (k_i G2) = (sum_i k_i s_i) G2 against the oracle's scalar multiplication
