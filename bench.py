@@ -393,6 +393,8 @@ def main():
     total_points = n * world * args.steps
     value = total_points / elapsed
     accum_avg_s = (accum_ms / accum_launches) * 1e-3 if accum_launches else float("nan")
+    precomputed = bool(not args.no_precompute)       # (log_n > 21 switches precomputation off above)
+    mads_per_add = 10 * (392 if precomputed else 288)
     achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
     # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
     # from the committed summary of the same command, profiles/r1_g_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
@@ -431,13 +433,14 @@ def main():
                      "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
                              "neighbouring step's kernels share the GPU (two-deep pipeline); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
                              "profiles/r1_g_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
-        # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products
-        # = 10 * 2*12*12 limb products; peak = measured v_mad_u64_u32 issue rate (profiles/r1_ubench_valu.txt:
-        # 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same k_accum launch time as above.
-        "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum (bucket accumulation)",
-                          "achieved": n * main_w * 2880 / accum_avg_s / 1e12 if accum_launches else None,
-                          "peak": 1.46e9 * 64 * 256 / 1e12, "unit": "T limb-products/s",
-                          "frac": (n * main_w * 2880 / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},
+        # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products; with
+        # precomputed bases the accumulation runs on 14 x 28-bit limbs (2 * 14 * 14 = 392 v_mad_u64_u32 per product, carry-free),
+        # otherwise on 12 x 32-bit limbs (288 mads + 288 add-with-carry).  peak = measured v_mad_u64_u32 issue rate
+        # (profiles/r1_ubench_valu.txt: 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same launch time as above.
+        "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum28 (bucket accumulation, 14 x 28-bit limbs)" if precomputed else "k_accum (bucket accumulation)",
+                          "achieved": n * main_w * mads_per_add / accum_avg_s / 1e12 if accum_launches else None,
+                          "peak": 1.46e9 * 64 * 256 / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
+                          "frac": (n * main_w * mads_per_add / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},
         "cpu_baseline": cpu_baseline,
     }
     if extras:

@@ -118,6 +118,94 @@ template <class P> __device__ __forceinline__ void mont_mul_asm_{N}(uint32_t *r,
     return holder + "\n" + call
 
 
+
+# ---------------------------------------------------------------- carry-free 14 x 28-bit product for Fp (R' = 2^392)
+P381 = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+N28, W28 = 14, 28
+MASK28 = (1 << W28) - 1
+
+
+def body28():
+    """Column sums of 28 products below 2^58 fit a 64-bit accumulator, so no v_addc follows the mads; per column one 64-bit shift
+    and one mask.  Operand limbs may be loose: limb bounds 2^Ea, 2^Eb with Ea + Eb <= 59.  Output: limbs below 2^28 (the top limb
+    holds the rest), value below a*b / 2^392 + p -- no final subtraction.  a, b are preserved."""
+    A = lambda i: f"v{i}"
+    B = lambda i: f"v{N28 + i}"
+    M = lambda i: f"v{2 * N28 + i}"
+    Pm = lambda i: f"s{i}"
+    INV, MSK = "s14", "s15"
+    lo, hi, pr, tmp = "v42", "v43", "v[42:43]", "v44"
+    ins = [f"v_mov_b32 {lo}, 0", f"v_mov_b32 {hi}, 0"]
+    for k in range(2 * N28 - 1):
+        for i in range(max(0, k - N28 + 1), min(k, N28 - 1) + 1):
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {B(k - i)}, {pr}")
+        for i in (range(0, k) if k < N28 else range(k - N28 + 1, N28)):
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {M(i)}, {Pm(k - i)}, {pr}")
+        if k < N28:
+            ins.append(f"v_mul_lo_u32 {tmp}, {lo}, {INV}")
+            ins.append(f"v_and_b32 {M(k)}, {MSK}, {tmp}")
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {M(k)}, {Pm(0)}, {pr}")
+        else:
+            ins.append(f"v_and_b32 {M(k - N28)}, {MSK}, {lo}")
+        ins.append(f"v_lshrrev_b64 {pr}, {W28}, {pr}")
+    ins.append(f"v_mov_b32 {M(N28 - 1)}, {lo}")
+    return ins
+
+
+def limbs28(v):
+    return [(v >> (W28 * i)) & MASK28 for i in range(N28 - 1)] + [v >> (W28 * (N28 - 1))]
+
+
+def redundant(c, lend):
+    """c*p with every limb but the top raised by lend * 2^28 (borrowed from the limb above): subtracting a value whose limbs are
+    below lend * 2^28 (top limb below the top limb here) never goes negative in any limb."""
+    k = limbs28(c * P381)
+    out = [k[0] + lend * (1 << W28)] + [k[i] + lend * (1 << W28) - lend for i in range(1, N28 - 1)] + [k[N28 - 1] - lend]
+    assert sum(x << (W28 * i) for i, x in enumerate(out)) == c * P381 and all(0 <= x < (1 << 32) for x in out)
+    return out
+
+
+def gen28():
+    p28 = limbs28(P381)
+    inv28 = (-pow(P381, -1, 1 << W28)) % (1 << W28)
+    ins = body28()
+    lines = ['s_branch .Lvsp_mm28_end', '.p2align 8', 'vsp_mm28:']
+    lines += [f's_mov_b32 s{i}, 0x{p28[i]:x}' for i in range(N28)] + [f's_mov_b32 s14, 0x{inv28:x}', f's_mov_b32 s15, 0x{MASK28:x}']
+    lines += ins + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm28_end:']
+    body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
+    vclob = ", ".join(f'"v{i}"' for i in range(45))
+    sclob = ", ".join(f'"s{i}"' for i in range(16))
+    n_mad = sum(1 for x in ins if x.startswith("v_mad"))
+    arr = lambda name, v: f"static constexpr uint32_t {name}[14] = {{" + ", ".join(f"0x{x:x}u" for x in v) + "};"
+    R1 = (1 << 392) % P381
+    consts = "\n".join([arr("FP28_P", p28), arr("FP28_ONE", limbs28(R1)), arr("FP28_R2", limbs28(R1 * R1 % P381)),
+                        arr("FP28_K8_L1", redundant(8, 1)), arr("FP28_K8_L4", redundant(8, 4)),
+                        arr("FP28_K32_L1", redundant(32, 1)), arr("FP28_K32_L4", redundant(32, 4))])
+    outs = ", ".join(f'"={{v{2 * N28 + i}}}"(r[{i}])' for i in range(N28))
+    inps = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N28)] + [f'"{{v{N28 + i}}}"(b[{i}])' for i in range(N28)])
+    return f"""// ---- Fp on 14 x 28-bit limbs, R' = 2^392: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v44 ----
+// constants: p; R' mod p (the Montgomery one); R'^2 mod p; and multiples of p in the redundant form used by the lazy subtractions
+// (FP28_Kc_Ll = c*p with every limb but the top raised by l * 2^28)
+{consts}
+template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul28_holder() {{
+    asm volatile(
+{body_txt}
+        :
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclob});
+}}
+// r = a*b*2^(-392) mod p as described at body28(); a and b are preserved
+__device__ __forceinline__ void mont_mul28_asm(uint32_t *r, const uint32_t *a, const uint32_t *b) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, vsp_mm28@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, vsp_mm28@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outs}
+        : {inps}
+        : "vcc", "scc", "s30", "s31", {sclob}, "v42", "v43", "v44");
+}}
+"""
+
 def main():
     text = '''// GENERATED by tools/gen_mont_asm.py -- do not edit.  See that file for the design notes.
 #pragma once
@@ -125,7 +213,7 @@ def main():
 
 namespace vsp {
 
-''' + gen(12) + "\n" + gen(8) + "\n}  // namespace vsp\n"
+''' + gen(12) + "\n" + gen(8) + "\n" + gen28() + "\n}  // namespace vsp\n"
     open(OUT, "w").write(text)
     print("wrote", os.path.normpath(OUT))
 

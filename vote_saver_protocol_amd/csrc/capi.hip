@@ -196,6 +196,7 @@ void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     if (b->d) hipFree(b->d);
+    if (b->d28) hipFree(b->d28);
     delete b;
 }
 
@@ -206,7 +207,7 @@ namespace vsp {
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot) {
     if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
     if (bases->pre_c) {
-        MsmPre pre{bases->n, first, bases->pre_c};
+        MsmPre pre{bases->n, first, bases->pre_c, bases->d28};
         if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
         return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
     }
@@ -239,6 +240,16 @@ int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) {
     VSP_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(b->d);
     b->d = table; b->pre_c = window_bits;
+    if (b->group == 1) {
+        // the accumulation kernel reads the table on 14 x 28-bit limbs (fp28.h); without that copy it falls back to the 12 x 32 form
+        long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
+        void *t28 = nullptr;
+        if (want && hipMalloc(&t28, (size_t)W * b->n * 112) == hipSuccess) {
+            rc = msm_g1_table28(ctx, (const G1Affine *)table, (size_t)W * b->n, t28);
+            if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) b->d28 = t28; else hipFree(t28);
+        }
+        hipGetLastError();
+    }
     return VSP_OK;
 }
 

@@ -43,7 +43,7 @@ struct MsmGeom {
     uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
 };
 // reference to the precomputed window multiples of resident bases
-struct MsmPre { size_t stride; size_t first; unsigned c; };
+struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), G1 only, or null
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
@@ -52,7 +52,7 @@ struct MsmWork {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
-    DevBuf buckets, partials, dims, winres, medium;
+    DevBuf buckets, partials, dims, winres, medium, redo;
     void *h_pinned = nullptr;
     void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
     hipEvent_t census_done = nullptr;
@@ -93,6 +93,7 @@ struct vsp_bases {
     void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
                             // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
     unsigned pre_c = 0;
+    void *d28 = nullptr;    // G1 with pre_c != 0: the table once more as Affine28 (14 x 28-bit limbs, fp28.h) for the accumulation kernel
 };
 
 // math::evaluation_domain<Fr>: the basic radix-2 domain (step = 0, m = big_m = 2^log_big) or the step radix-2 domain
@@ -171,6 +172,7 @@ int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, si
 int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
 int msm_g1_precompute(vsp_ctx *ctx, G1Affine *table, size_t n, unsigned c);
 int msm_g2_precompute(vsp_ctx *ctx, G2Affine *table, size_t n, unsigned c);
+int msm_g1_table28(vsp_ctx *ctx, const G1Affine *table, size_t count, void *d_out /* count x 112 bytes */);
 int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
 int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);

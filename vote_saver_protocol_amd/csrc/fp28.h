@@ -1,0 +1,154 @@
+// Fp on 14 x 28-bit limbs with lazy reduction, for the G1 bucket accumulation over precomputed window multiples.
+//
+// Why: with 28-bit limbs a column of the Montgomery product (28 partial products below 2^58) fits a 64-bit accumulator, so the
+// v_addc_co_u32 that follows every v_mad_u64_u32 of the 12 x 32-bit routine disappears, and so does the final subtraction:
+// 2284 cycles per wave-product against 3149 (profiles/r1_ubench_mont.txt).  The price is a discipline of bounds, kept here:
+//
+//   value form     Montgomery with R' = 2^392:  x stands for x * 2^392 mod p
+//   "tight"        limbs below 2^28 (the top limb holds the rest) -- every product output, every normalised value
+//   "loose"        limbs below 2^30 (results of the lazy subtractions a + K - b)
+//   products       need limb bounds 2^Ea, 2^Eb with Ea + Eb <= 59 and values below 2^388; output tight, value < a*b/2^392 + p
+//   a - b          = a + K - b limb by limb, K a multiple of p in a redundant form whose limbs dominate those of b
+//                  (FP28_K8_L1: b tight, b < 4p ... FP28_K32_L4: b loose, b < 16p); no borrow ever crosses a limb
+//
+// Invariants of the accumulator between mixed additions (checked against the formulas in madd28 below):
+//   X tight, value < 9.1 p;   Y loose, value < 9.1 p;   ZZ, ZZZ tight, value < 1.6 p      (inf: all limbs zero)
+// Everything outside the accumulation kernel keeps the 12 x 32-bit form; conversion happens once per table entry (at
+// precomputation) and once per bucket part (at the store).
+#pragma once
+#include "curve.h"
+
+namespace vsp {
+
+struct Fp28 { uint32_t l[14]; };                       // 56 bytes (no over-alignment: that would pad it to 64)
+struct alignas(16) Affine28 { Fp28 x, y; };          // 112 bytes = 7 x 16
+static_assert(sizeof(Fp28) == 56 && sizeof(Affine28) == 112, "table rows are 112 bytes");
+struct XYZZ28 { Fp28 X, Y, ZZ, ZZZ; };
+
+#if defined(__HIP_DEVICE_COMPILE__)        // the product routine exists in the device pass only; kernels guard their bodies alike
+__device__ __forceinline__ Fp28 fp28_zero() { Fp28 r; for (int i = 0; i < 14; i++) r.l[i] = 0; return r; }
+__device__ __forceinline__ Fp28 fp28_const(const uint32_t (&c)[14]) { Fp28 r; for (int i = 0; i < 14; i++) r.l[i] = c[i]; return r; }
+__device__ __forceinline__ bool fp28_all_zero(const Fp28 &a) { uint32_t o = 0; for (int i = 0; i < 14; i++) o |= a.l[i]; return o == 0; }
+__device__ __forceinline__ bool fp28_equals(const Fp28 &a, const uint32_t (&c)[14]) { uint32_t o = 0; for (int i = 0; i < 14; i++) o |= a.l[i] ^ c[i]; return o == 0; }
+
+__device__ __forceinline__ Fp28 mul28(const Fp28 &a, const Fp28 &b) {
+    Fp28 r;
+    __builtin_amdgcn_sched_barrier(0);          // the machine scheduler of this toolchain crashes when it moves code across the call
+    mont_mul28_asm(r.l, a.l, b.l);
+    __builtin_amdgcn_sched_barrier(0);
+    (void)&mont_mul28_holder<0>;
+    return r;
+}
+// a + K - b, limb by limb (see the header for which K goes with which b)
+__device__ __forceinline__ Fp28 sub28(const Fp28 &a, const uint32_t (&K)[14], const Fp28 &b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + K[i] - b.l[i];
+    return r;
+}
+__device__ __forceinline__ Fp28 neg28(const uint32_t (&K)[14], const Fp28 &b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = K[i] - b.l[i];
+    return r;
+}
+// carry pass: loose -> tight (same value)
+__device__ __forceinline__ Fp28 norm28(const Fp28 &a) {
+    Fp28 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) { uint32_t t = a.l[i] + c; r.l[i] = t & 0x0FFFFFFFu; c = t >> 28; }
+    r.l[13] = a.l[13] + c;
+    return r;
+}
+// a product output (tight, value < 2p) is congruent to zero exactly when it is 0 or p
+__device__ __forceinline__ bool fp28_product_is_zero(const Fp28 &a) { return fp28_all_zero(a) || fp28_equals(a, FP28_P); }
+
+// ---- conversion to and from the library's 12 x 32-bit Montgomery form (R = 2^384)
+__device__ __forceinline__ Fp28 fp_to_fp28(const Fp &m) {
+    __builtin_amdgcn_sched_barrier(0);
+    Fp c = from_mont(m);                       // canonical residue, 12 x 32 bits
+    __builtin_amdgcn_sched_barrier(0);
+    Fp28 s;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int bit = 28 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t v = c.l[w];
+        if (w + 1 < 12) v |= (uint64_t)c.l[w + 1] << 32;
+        s.l[i] = (uint32_t)(v >> sh) & (i < 13 ? 0x0FFFFFFFu : 0xFFFFFFFFu);
+    }
+    return mul28(s, fp28_const(FP28_R2));       // x * R'^2 / R' = x * R'
+}
+// any value within the invariants above (loose limbs allowed)
+__device__ __forceinline__ Fp fp28_to_fp(const Fp28 &x) {
+    Fp28 one = fp28_zero(); one.l[0] = 1;
+    Fp28 v = mul28(x, one);                     // plain residue, tight, in [0, p + small)
+    // conditional subtraction of p (exact: v is tight, so the limbs compare like digits)
+    Fp28 d; uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint32_t t = v.l[i] - FP28_P[i] - borrow;
+        borrow = (i < 13) ? ((t >> 28) & 1u) : (t >> 31);      // limbs < 2^28: a wrapped difference has bit 28 (top limb: bit 31) set
+        d.l[i] = (i < 13) ? (t & 0x0FFFFFFFu) : t;
+    }
+    if (!borrow) v = d;
+    Fp c;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const int lo = 28 * i - 32 * w;     // position of limb i's bit 0 inside word w
+            if (lo > -28 && lo < 32) acc |= lo >= 0 ? (v.l[i] << lo) : (v.l[i] >> (-lo));
+        }
+        c.l[w] = acc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Fp out = to_mont(c);
+    __builtin_amdgcn_sched_barrier(0);
+    return out;
+}
+
+__device__ __forceinline__ bool is_inf28(const Affine28 &p) { return fp28_all_zero(p.x) && fp28_all_zero(p.y); }
+__device__ __forceinline__ bool is_inf28(const XYZZ28 &p) { return fp28_all_zero(p.ZZ); }
+__device__ __forceinline__ XYZZ28 xyzz28_inf() { XYZZ28 r; r.X = r.Y = r.ZZ = r.ZZZ = fp28_zero(); return r; }
+__device__ __forceinline__ XYZZ<Fp> xyzz28_to_fp(const XYZZ28 &a) {
+    XYZZ<Fp> r;
+    if (is_inf28(a)) return XYZZ<Fp>::inf();
+    r.X = fp28_to_fp(a.X); r.Y = fp28_to_fp(a.Y); r.ZZ = fp28_to_fp(a.ZZ); r.ZZZ = fp28_to_fp(a.ZZZ);
+    return r;
+}
+
+// acc += q (q affine, optionally negated): the mixed addition of curve.h (madd-2008-s) under the bounds of the header.
+//   U2 = x2 ZZ1, S2 = y2 ZZZ1, P = U2 - X1, R = S2 - Y1, PP = P^2, PPP = P PP, Q = X1 PP,
+//   X3 = R^2 - (PPP + 2Q), Y3 = R (Q - X3) - Y1 PPP, ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP
+// Returns false -- leaving acc untouched -- in the exceptional case of equal x (doubling or cancellation): the caller hands the
+// whole bucket part to the generic 12 x 32-bit kernel instead (a call or the generic formulas inline would poison the hot loop's
+// register allocation, and this toolchain's scheduler crashes on them).
+__device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool negate) {
+    if (is_inf28(q)) return true;
+    Fp28 qy = negate ? neg28(FP28_K8_L1, q.y) : q.y;                     // loose, < 8p
+    if (is_inf28(acc)) { acc.X = q.x; acc.Y = qy; acc.ZZ = fp28_const(FP28_ONE); acc.ZZZ = acc.ZZ; return true; }
+    Fp28 U2 = mul28(q.x, acc.ZZ);
+    Fp28 S2 = mul28(qy, acc.ZZZ);
+    Fp28 P = norm28(sub28(U2, FP28_K32_L1, acc.X));                      // X1 tight, < 16p  ->  P tight, < 33.1p
+    Fp28 PP = mul28(P, P);                                               // < 1.6p
+    if (fp28_product_is_zero(PP)) return false;
+    Fp28 R = norm28(sub28(S2, FP28_K32_L4, acc.Y));                      // Y1 loose, < 16p  ->  R tight, < 33.1p
+    Fp28 PPP = mul28(P, PP);
+    Fp28 Q = mul28(acc.X, PP);
+    Fp28 s;                                                              // PPP + 2Q: limbs < 3 * 2^28, value < 4p
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
+    Fp28 X3 = norm28(sub28(mul28(R, R), FP28_K8_L4, s));                 // tight, < 9.1p
+    Fp28 t1 = mul28(R, sub28(Q, FP28_K32_L1, X3));                       // (Q - X3) loose, < 33.1p
+    Fp28 t2 = mul28(acc.Y, PPP);
+    acc.Y = sub28(t1, FP28_K8_L1, t2);                                   // loose, < 9.1p
+    acc.X = X3;
+    acc.ZZ = mul28(acc.ZZ, PP);
+    acc.ZZZ = mul28(acc.ZZZ, PPP);
+    return true;
+}
+#endif
+
+}  // namespace vsp
