@@ -93,7 +93,7 @@ struct vsp_bases {
     void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
                             // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
     unsigned pre_c = 0;
-    void *d28 = nullptr;    // G1 with pre_c != 0: the table once more as Affine28 (14 x 28-bit limbs, fp28.h) for the accumulation kernel
+    void *d28 = nullptr;    // G1: the same array (or table) once more as Affine28 (14 x 28-bit limbs, fp28.h) for the accumulation kernel
 };
 
 // math::evaluation_domain<Fr>: the basic radix-2 domain (step = 0, m = big_m = 2^log_big) or the step radix-2 domain
@@ -169,7 +169,8 @@ int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, const vsp_domain *d
 // MSM on device-resident Montgomery bases; result as host XYZZ (Montgomery, 64-bit limbs)
 int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);
 int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp2> *out);
-int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
+int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre,
+                  const void *plain_table28 = nullptr);   // plain bases (pre == null): the same points as Affine28, or null
 int msm_g1_precompute(vsp_ctx *ctx, G1Affine *table, size_t n, unsigned c);
 int msm_g2_precompute(vsp_ctx *ctx, G2Affine *table, size_t n, unsigned c);
 int msm_g1_table28(vsp_ctx *ctx, const G1Affine *table, size_t count, void *d_out /* count x 112 bytes */);
