@@ -397,11 +397,11 @@ def main():
     mads_per_add = 10 * (392 if precomputed else 288)
     achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
     # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
-    # from the committed summary of the same command, profiles/r1_g_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
+    # from the committed summary of the same command, profiles/r1_h_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
     try:
         if args.log_n == 20:
-            with open(os.path.join(ROOT, "profiles", "r1_g_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1_h_pmc_hbm_traffic.json")) as f:
                 traffic = json.load(f)["k_accum_G1_2p20"]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -426,13 +426,13 @@ def main():
                    "precompute_once_s": precompute_s,
                    "plain_bases_ms_per_step": plain_ms, "plain_bases_points_per_s": (n * world / (plain_ms * 1e-3)) if plain_ms else None},
         "verified_bit_exact": verified,
-        "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation)",
+        "roofline": {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation, 28-bit limbs)" if precomputed else "k_accum (bucket accumulation)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
                      "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
-                             "neighbouring step's kernels share the GPU (two-deep pipeline); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
-                             "profiles/r1_g_pmc_hbm_traffic.json: every base is gathered once per window (16 x 96 B), see DESIGN.md"},
+                             "neighbouring step's kernels share the GPU (three MSMs in flight); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
+                             "profiles/r1_h_pmc_hbm_traffic.json: every base is gathered once per window (16 rows of 112 B from the 28-bit-limb table), see DESIGN.md"},
         # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products; with
         # precomputed bases the accumulation runs on 14 x 28-bit limbs (2 * 14 * 14 = 392 v_mad_u64_u32 per product, carry-free),
         # otherwise on 12 x 32-bit limbs (288 mads + 288 add-with-carry).  peak = measured v_mad_u64_u32 issue rate
