@@ -48,3 +48,27 @@ def test_field_golden_and_random(ctx, field, mod, nl, key):
     assert ints(run(ctx, field, 4, a, b), nl) == [x * y % mod for x, y in zip(A, B)]
     n_inv = 300
     assert ints(run(ctx, field, 5, a[:n_inv], b[:n_inv]), nl) == [pow(x, mod - 2, mod) for x in A[:n_inv]]
+
+
+def test_fp28_lazy_field_against_big_integers(ctx):
+    """The 14 x 28-bit field of the G1 accumulation (carry-free product, lazy subtractions against redundant multiples of p):
+    round trip, product, and each subtraction form used by the mixed addition, on edge values and random ones."""
+    mod, nl = o.P, 6
+    g = load_golden("field.json")["fp"]
+    A = [int(c["a"], 16) for c in g]; B = [int(c["b"], 16) for c in g]
+    edge = [0, 1, 2, mod - 1, mod - 2, (mod - 1) // 2, (1 << 380) - 1, (1 << 364) - 1, (1 << 28) - 1, 1 << 28, (1 << 56) - 1, mod >> 1, 3]
+    for x in edge:
+        for y in edge:
+            A.append(x % mod); B.append(y % mod)
+    rng = np.random.default_rng(28)
+    for _ in range(20000):
+        A.append(int.from_bytes(rng.bytes(48), "little") % mod); B.append(int.from_bytes(rng.bytes(48), "little") % mod)
+    for k in range(0, 381, 3):                         # limbs of all ones / single bits around every 28-bit boundary
+        A.append(((1 << k) - 1) % mod); B.append((mod - (1 << (k % 377))) % mod)
+    a, b = limbs_arr(A, nl), limbs_arr(B, nl)
+    assert ints(run(ctx, 0, 6, a, b), nl) == A
+    assert ints(run(ctx, 0, 7, a, b), nl) == [x * y % mod for x, y in zip(A, B)]
+    assert ints(run(ctx, 0, 8, a, b), nl) == [(x - y) * (x - y) % mod for x, y in zip(A, B)]
+    assert ints(run(ctx, 0, 9, a, b), nl) == [(x - 3 * y) % mod for x, y in zip(A, B)]
+    assert ints(run(ctx, 0, 10, a, b), nl) == [x * (y - x) % mod for x, y in zip(A, B)]
+    assert ints(run(ctx, 0, 11, a, b), nl) == [(-y) * x % mod for x, y in zip(A, B)]

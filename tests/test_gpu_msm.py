@@ -192,6 +192,35 @@ def test_msm_g2_2p18_discrete_log_identity(ctx, cref, precompute):
         B.free(); ctx.dfree(d_b); ctx.dfree(d_k); ctx.dfree(d_s)
 
 
+@pytest.mark.parametrize("precompute", [False, True])
+def test_msm_duplicate_bases_take_the_equal_x_path(ctx, cref, precompute):
+    """Only ten distinct points (and their negatives) among 4000 bases: buckets keep meeting equal x -- doublings and
+    cancellations -- which the 28-bit-limb accumulation hands back to the generic kernel part by part."""
+    n = 4000
+    few = cref.g1_batch_mul_gen(rand_fr_array(10, seed=71))
+    neg = few.copy()
+    for i in range(10):
+        neg[i] = g1_limbs(o.G1.neg(o.g1_from_limbs(few[i])))
+    rng = np.random.default_rng(72)
+    pick = rng.integers(0, 20, size=n)
+    bases = np.stack([few[k] if k < 10 else neg[k - 10] for k in pick])
+    bases[17] = 0                                              # an infinity among them
+    ss = rand_fr_array(n, seed=73)
+    ss[:500] = 0; ss[:500, 0] = rng.integers(0, 3, size=500, dtype=np.uint64)
+    exp = cref.msm_g1(bases, ss, mixed=True)
+    B = ctx.upload_bases(bases, 1)
+    if precompute:
+        B.precompute(0)
+    d_s = ctx.to_device(ss)
+    try:
+        got, _ = B.msm(d_s)
+        assert np.array_equal(got, exp)
+        part, _ = B.msm(d_s + 32 * 100, n=3000, first=100)
+        assert np.array_equal(part, cref.msm_g1(bases[100:3100], ss[100:3100], mixed=True))
+    finally:
+        ctx.dfree(d_s); B.free()
+
+
 def test_msm_pipelined_slots_and_shared_streams(ctx, cref):
     """vsp_msm_launch / vsp_msm_finish_jacobian: several multi-exponentiations in flight on their own streams (G1 and G2
     mixed), finished out of order; results identical to the blocking calls and to the oracle."""

@@ -1,6 +1,7 @@
 // extern "C" surface of libvsp_hip.so (declared in include/vsp.h): context, device memory, MSM / NTT /
 // witness_map entry points, Jacobian record folding and the ZCash point compression.
 #include "common.h"
+#include "fp28.h"
 
 namespace vsp {
 
@@ -66,6 +67,26 @@ template <class F> __global__ __launch_bounds__(64) void k_selftest_field(int op
     out[i] = r;
 }
 
+// the 14 x 28-bit lazy field of the G1 accumulation (fp28.h) against the 12 x 32-bit one, on canonical inputs:
+//   op 6 round trip, 7 product, 8 (x - y)^2 through the K32 subtraction and a carry pass, 9 x - 3y through the K8 subtraction of a
+//   lazy sum, 10 x (y - x) with a loose operand, 11 -y x through the negation used for signed digits
+__global__ __launch_bounds__(64) void k_selftest_fp28(int op, const Fp *a, const Fp *b, Fp *out, size_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp28 x = fp_to_fp28(to_mont(a[i])), y = fp_to_fp28(to_mont(b[i])), r;
+    switch (op) {
+        case 6: r = x; break;
+        case 7: r = mul28(x, y); break;
+        case 8: { Fp28 d = norm28(sub28(x, FP28_K32_L1, y)); r = mul28(d, d); } break;
+        case 9: { Fp28 s3; for (int k = 0; k < 14; k++) s3.l[k] = y.l[k] + 2u * y.l[k]; r = norm28(sub28(x, FP28_K8_L4, s3)); } break;
+        case 10: r = mul28(x, sub28(y, FP28_K32_L1, x)); break;
+        default: r = mul28(neg28(FP28_K8_L1, y), x); break;
+    }
+    out[i] = from_mont(fp28_to_fp(r));
+#endif
+}
+
 }  // namespace vsp
 
 using namespace vsp;
@@ -74,7 +95,7 @@ extern "C" {
 
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     if (!ctx) return VSP_ERR_ARG;
-    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 5) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
+    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 11 || (op > 5 && field != 0)) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
     VSP_HIP(hipSetDevice(ctx->device));
     size_t esz = field == 0 ? sizeof(Fp) : sizeof(Fr);
     DevBuf da, db, dc;
@@ -83,7 +104,8 @@ int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const
         hipMemcpyAsync(da.p, a, n * esz, hipMemcpyHostToDevice, ctx->stream);
         hipMemcpyAsync(db.p, b, n * esz, hipMemcpyHostToDevice, ctx->stream);
         unsigned blocks = (unsigned)((n + 63) / 64);
-        if (field == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fp>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
+        if (field == 0 && op > 5) hipLaunchKernelGGL(k_selftest_fp28, dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
+        else if (field == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fp>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fr>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fr *)da.p, (const Fr *)db.p, (Fr *)dc.p, n);
         hipMemcpyAsync(out, dc.p, n * esz, hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "selftest: kernel failed");
