@@ -57,7 +57,10 @@ int vsp_synchronize(vsp_ctx *ctx);
  * accumulation kernel, summed since the last vsp_stats_reset), "msm_accum_launches", "msm_window_bits". */
 double vsp_get_stat(vsp_ctx *ctx, const char *name);
 void vsp_stats_reset(vsp_ctx *ctx);
-/* tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold) */
+/* tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
+ * the H multi-exponentiation before the witness ones), "msm_fp28" (1: G1 bases are kept a second time on 14 x 28-bit limbs for the
+ * accumulation kernel -- 112 bytes per point on top of the 96; 0 before an upload / precomputation leaves that copy out and the
+ * 12 x 32-bit kernel runs) */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
 
 /* ---- raw device memory helpers (for callers without torch) --------------------------------- */
