@@ -12,8 +12,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = v.Context(0)
-pool1 = cref.g1_batch_mul_gen(rand_fr_array(30000, seed=1000 + seed))
-pool2 = cref.g2_batch_mul_gen(rand_fr_array(3000, seed=2000 + seed))
+POOL1 = int(os.environ.get("POOL1", "30000")); POOL2 = int(os.environ.get("POOL2", "3000"))
+pool1 = cref.g1_batch_mul_gen(rand_fr_array(POOL1, seed=1000 + seed))
+pool2 = cref.g2_batch_mul_gen(rand_fr_array(POOL2, seed=2000 + seed))
 t0 = time.time(); it = 0; stats = {}
 while time.time() - t0 < budget:
     it += 1

@@ -15,7 +15,7 @@ ctx = v.Context(0)
 t0 = time.time(); it = 0; kinds = {"basic_radix2": 0, "step_radix2": 0}
 while time.time() - t0 < budget:
     it += 1
-    nc = int(np.exp(rng.uniform(np.log(2), np.log(5000))))
+    nc = int(np.exp(rng.uniform(np.log(2), np.log(float(os.environ.get("MAX_NC", "5000"))))))
     ni = int(rng.integers(0, min(30, nc) + 1))
     s = int(rng.integers(1, 1 << 30))
     cs, wit = cref.R1CS.synth(nc, ni, s)
