@@ -12,7 +12,10 @@
 //                  (FP28_K8_L1: b tight, b < 4p ... FP28_K32_L4: b loose, b < 16p); no borrow ever crosses a limb
 //
 // Invariants of the accumulator between mixed additions (checked against the formulas in madd28 below):
-//   X tight, value < 9.1 p;   Y loose, value < 9.1 p;   ZZ, ZZZ tight, value < 1.6 p      (inf: all limbs zero)
+//   X tight, value < 9.5 p;   Y loose, value < 9.5 p;   ZZ, ZZZ tight, value < 1.1 p      (inf: all limbs zero)
+// Derivation (p / 2^392 = 1 / 2521):  P = U2 + 32p - X < 33.1p,  PP = P^2 < (33.1^2 / 2521 + 1) p = 1.44p,  PPP, Q < 1.02p,
+//   R = S2 + 32p - Y < 33.5p,  R^2 < 1.45p,  s = PPP + 2Q < 3.1p (limbs < 3 * 2^28),  X3 = R^2 + 8p - s < 9.5p,
+//   Q - X3 + 32p < 33.1p (limbs < 2^30),  t1 = R (Q - X3) < 1.45p,  t2 = Y1 PPP < 1.01p,  Y3 = t1 + 8p - t2 < 9.5p (limbs < 2^30).
 // Everything outside the accumulation kernel keeps the 12 x 32-bit form; conversion happens once per table entry (at
 // precomputation) and once per bucket part (at the store).
 #pragma once
@@ -132,7 +135,7 @@ __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool nega
     Fp28 U2 = mul28(q.x, acc.ZZ);
     Fp28 S2 = mul28(qy, acc.ZZZ);
     Fp28 P = norm28(sub28(U2, FP28_K32_L1, acc.X));                      // X1 tight, < 16p  ->  P tight, < 33.1p
-    Fp28 PP = mul28(P, P);                                               // < 1.6p
+    Fp28 PP = mul28(P, P);                                               // < 1.44p
     if (fp28_product_is_zero(PP)) return false;
     Fp28 R = norm28(sub28(S2, FP28_K32_L4, acc.Y));                      // Y1 loose, < 16p  ->  R tight, < 33.1p
     Fp28 PPP = mul28(P, PP);
@@ -140,10 +143,10 @@ __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool nega
     Fp28 s;                                                              // PPP + 2Q: limbs < 3 * 2^28, value < 4p
 #pragma unroll
     for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
-    Fp28 X3 = norm28(sub28(mul28(R, R), FP28_K8_L4, s));                 // tight, < 9.1p
+    Fp28 X3 = norm28(sub28(mul28(R, R), FP28_K8_L4, s));                 // tight, < 9.5p
     Fp28 t1 = mul28(R, sub28(Q, FP28_K32_L1, X3));                       // (Q - X3) loose, < 33.1p
     Fp28 t2 = mul28(acc.Y, PPP);
-    acc.Y = sub28(t1, FP28_K8_L1, t2);                                   // loose, < 9.1p
+    acc.Y = sub28(t1, FP28_K8_L1, t2);                                   // loose, < 9.5p
     acc.X = X3;
     acc.ZZ = mul28(acc.ZZ, PP);
     acc.ZZZ = mul28(acc.ZZZ, PPP);
