@@ -210,6 +210,8 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     if args.window_bits:
         ctx.set_option("msm_window_bits", args.window_bits)
+    if os.environ.get("VSP_MSM_SPLIT"):
+        ctx.set_option("msm_split", int(os.environ["VSP_MSM_SPLIT"]))      # experiment knob: points per bucket part
     if args.prove_h_first >= 0:
         ctx.set_option("prove_h_first", args.prove_h_first)
 
