@@ -399,7 +399,7 @@ def main():
     value = total_points / elapsed
     accum_avg_s = (accum_ms / accum_launches) * 1e-3 if accum_launches else float("nan")
     precomputed = bool(not args.no_precompute)       # (log_n > 21 switches precomputation off above)
-    mads_per_add = 10 * (392 if precomputed else 288)
+    mads_per_add = (8 * 392 + 588) if True else 0      # 28-bit-limb accumulation (plain and precomputed G1 bases): 8 products + 1 dual product
     achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
     # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
     # from the committed summary of the same command, profiles/r1_h_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
@@ -431,7 +431,7 @@ def main():
                    "precompute_once_s": precompute_s,
                    "plain_bases_ms_per_step": plain_ms, "plain_bases_points_per_s": (n * world / (plain_ms * 1e-3)) if plain_ms else None},
         "verified_bit_exact": verified,
-        "roofline": {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation, 28-bit limbs)" if precomputed else "k_accum (bucket accumulation)",
+        "roofline": {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation, 28-bit limbs)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
@@ -439,10 +439,10 @@ def main():
                              "neighbouring step's kernels share the GPU (three MSMs in flight); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
                              "profiles/r1_h_pmc_hbm_traffic.json: every base is gathered once per window (16 rows of 112 B from the 28-bit-limb table), see DESIGN.md"},
         # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products; with
-        # precomputed bases the accumulation runs on 14 x 28-bit limbs (2 * 14 * 14 = 392 v_mad_u64_u32 per product, carry-free),
-        # otherwise on 12 x 32-bit limbs (288 mads + 288 add-with-carry).  peak = measured v_mad_u64_u32 issue rate
+        # the accumulation runs on 14 x 28-bit limbs: 2 * 14 * 14 = 392 v_mad_u64_u32 per product, carry-free, and one dual product
+        # a*b + c*d with a single reduction (588) -- 3724 per mixed addition.  peak = measured v_mad_u64_u32 issue rate
         # (profiles/r1_ubench_valu.txt: 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same launch time as above.
-        "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum28 (bucket accumulation, 14 x 28-bit limbs)" if precomputed else "k_accum (bucket accumulation)",
+        "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum28 (bucket accumulation, 14 x 28-bit limbs)",
                           "achieved": n * main_w * mads_per_add / accum_avg_s / 1e12 if accum_launches else None,
                           "peak": 1.46e9 * 64 * 256 / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
                           "frac": (n * main_w * mads_per_add / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},

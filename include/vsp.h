@@ -209,7 +209,7 @@ int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d
 
 /* ---- diagnostics ---------------------------------------------------------------------------------
  * Elementwise field arithmetic on the GPU over n canonical values (host buffers): field 0 = Fp (6 limbs),
- * 1 = Fr (4 limbs); op 0 mul, 1 add, 2 sub, 3 sqr(a), 4 canonical-times-Montgomery product, 5 inverse(a); Fp only: ops 6..11
+ * 1 = Fr (4 limbs); op 0 mul, 1 add, 2 sub, 3 sqr(a), 4 canonical-times-Montgomery product, 5 inverse(a); Fp only: ops 6..12
  * exercise the 14 x 28-bit lazy field of the G1 accumulation (round trip, product, the lazy subtractions and the negation).
  * Lets the tests check the kernels' Montgomery arithmetic directly against known-answer vectors. */
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);

@@ -72,3 +72,4 @@ def test_fp28_lazy_field_against_big_integers(ctx):
     assert ints(run(ctx, 0, 9, a, b), nl) == [(x - 3 * y) % mod for x, y in zip(A, B)]
     assert ints(run(ctx, 0, 10, a, b), nl) == [x * (y - x) % mod for x, y in zip(A, B)]
     assert ints(run(ctx, 0, 11, a, b), nl) == [(-y) * x % mod for x, y in zip(A, B)]
+    assert ints(run(ctx, 0, 12, a, b), nl) == [(x * (y - x) - y * x) % mod for x, y in zip(A, B)]

@@ -125,20 +125,28 @@ N28, W28 = 14, 28
 MASK28 = (1 << W28) - 1
 
 
-def body28():
+def body28(dual=False):
     """Column sums of 28 products below 2^58 fit a 64-bit accumulator, so no v_addc follows the mads; per column one 64-bit shift
     and one mask.  Operand limbs may be loose: limb bounds 2^Ea, 2^Eb with Ea + Eb <= 59.  Output: limbs below 2^28 (the top limb
-    holds the rest), value below a*b / 2^392 + p -- no final subtraction.  a, b are preserved."""
+    holds the rest), value below a*b / 2^392 + p -- no final subtraction.  a, b are preserved.
+    dual: a*b + c*d into the same column accumulators, one reduction (the sum of the two groups of 14 products must stay
+    below 2^64 - 2^60: e.g. limb bounds 28+30 and 31+28)."""
+    nin = 4 if dual else 2
     A = lambda i: f"v{i}"
     B = lambda i: f"v{N28 + i}"
-    M = lambda i: f"v{2 * N28 + i}"
+    C = lambda i: f"v{2 * N28 + i}"
+    D = lambda i: f"v{3 * N28 + i}"
+    M = lambda i: f"v{nin * N28 + i}"
     Pm = lambda i: f"s{i}"
     INV, MSK = "s14", "s15"
-    lo, hi, pr, tmp = "v42", "v43", "v[42:43]", "v44"
+    base = (nin + 1) * N28
+    lo, hi, pr, tmp = f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]", f"v{base + 2}"
     ins = [f"v_mov_b32 {lo}, 0", f"v_mov_b32 {hi}, 0"]
     for k in range(2 * N28 - 1):
         for i in range(max(0, k - N28 + 1), min(k, N28 - 1) + 1):
             ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {B(k - i)}, {pr}")
+            if dual:
+                ins.append(f"v_mad_u64_u32 {pr}, vcc, {C(i)}, {D(k - i)}, {pr}")
         for i in (range(0, k) if k < N28 else range(k - N28 + 1, N28)):
             ins.append(f"v_mad_u64_u32 {pr}, vcc, {M(i)}, {Pm(k - i)}, {pr}")
         if k < N28:
@@ -183,6 +191,17 @@ def gen28():
                         arr("FP28_K32_L1", redundant(32, 1)), arr("FP28_K32_L4", redundant(32, 4))])
     outs = ", ".join(f'"={{v{2 * N28 + i}}}"(r[{i}])' for i in range(N28))
     inps = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N28)] + [f'"{{v{N28 + i}}}"(b[{i}])' for i in range(N28)])
+    # dual variant
+    ins2 = body28(dual=True)
+    lines2 = ['s_branch .Lvsp_mm28x2_end', '.p2align 8', 'vsp_mm28x2:']
+    lines2 += [f's_mov_b32 s{i}, 0x{p28[i]:x}' for i in range(N28)] + [f's_mov_b32 s14, 0x{inv28:x}', f's_mov_b32 s15, 0x{MASK28:x}']
+    lines2 += ins2 + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm28x2_end:']
+    body2_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines2)
+    vclob2 = ", ".join(f'"v{i}"' for i in range(5 * N28 + 3))
+    outs2 = ", ".join(f'"={{v{4 * N28 + i}}}"(r[{i}])' for i in range(N28))
+    inps2 = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N28)] + [f'"{{v{N28 + i}}}"(b[{i}])' for i in range(N28)] +
+                      [f'"{{v{2 * N28 + i}}}"(c[{i}])' for i in range(N28)] + [f'"{{v{3 * N28 + i}}}"(d[{i}])' for i in range(N28)])
+    n_mad2 = sum(1 for x in ins2 if x.startswith("v_mad"))
     return f"""// ---- Fp on 14 x 28-bit limbs, R' = 2^392: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v44 ----
 // constants: p; R' mod p (the Montgomery one); R'^2 mod p; and multiples of p in the redundant form used by the lazy subtractions
 // (FP28_Kc_Ll = c*p with every limb but the top raised by l * 2^28)
@@ -203,6 +222,23 @@ __device__ __forceinline__ void mont_mul28_asm(uint32_t *r, const uint32_t *a, c
         : {outs}
         : {inps}
         : "vcc", "scc", "s30", "s31", {sclob}, "v42", "v43", "v44");
+}}
+// ---- the same for a*b + c*d with one reduction: {n_mad2} v_mad_u64_u32, {len(ins2)} instructions; operands v0..v55 (preserved), result v56..v69 ----
+template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul28x2_holder() {{
+    asm volatile(
+{body2_txt}
+        :
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclob2});
+}}
+__device__ __forceinline__ void mont_mul28x2_asm(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, vsp_mm28x2@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, vsp_mm28x2@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outs2}
+        : {inps2}
+        : "vcc", "scc", "s30", "s31", {sclob}, "v70", "v71", "v72");
 }}
 """
 

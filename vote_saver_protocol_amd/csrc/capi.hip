@@ -69,7 +69,7 @@ template <class F> __global__ __launch_bounds__(64) void k_selftest_field(int op
 
 // the 14 x 28-bit lazy field of the G1 accumulation (fp28.h) against the 12 x 32-bit one, on canonical inputs:
 //   op 6 round trip, 7 product, 8 (x - y)^2 through the K32 subtraction and a carry pass, 9 x - 3y through the K8 subtraction of a
-//   lazy sum, 10 x (y - x) with a loose operand, 11 -y x through the negation used for signed digits
+//   lazy sum, 10 x (y - x) with a loose operand, 11 -y x through the negation used for signed digits, 12 x (y - x) - y x as one dual product
 __global__ __launch_bounds__(64) void k_selftest_fp28(int op, const Fp *a, const Fp *b, Fp *out, size_t n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64) void k_selftest_fp28(int op, const Fp *a, const
         case 8: { Fp28 d = norm28(sub28(x, FP28_K32_L1, y)); r = mul28(d, d); } break;
         case 9: { Fp28 s3; for (int k = 0; k < 14; k++) s3.l[k] = y.l[k] + 2u * y.l[k]; r = norm28(sub28(x, FP28_K8_L4, s3)); } break;
         case 10: r = mul28(x, sub28(y, FP28_K32_L1, x)); break;
-        default: r = mul28(neg28(FP28_K8_L1, y), x); break;
+        case 11: r = mul28(neg28(FP28_K8_L1, y), x); break;
+        default: r = mul28x2(x, sub28(y, FP28_K32_L1, x), neg28(FP28_K32_L1, y), x); break;    // op 12: x (y - x) - y x through the dual product
     }
     out[i] = from_mont(fp28_to_fp(r));
 #endif
@@ -95,7 +96,7 @@ extern "C" {
 
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
     if (!ctx) return VSP_ERR_ARG;
-    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 11 || (op > 5 && field != 0)) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
+    if (!a || !b || !out || (field != 0 && field != 1) || op < 0 || op > 12 || (op > 5 && field != 0)) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
     VSP_HIP(hipSetDevice(ctx->device));
     size_t esz = field == 0 ? sizeof(Fp) : sizeof(Fr);
     DevBuf da, db, dc;

@@ -12,10 +12,10 @@
 //                  (FP28_K8_L1: b tight, b < 4p ... FP28_K32_L4: b loose, b < 16p); no borrow ever crosses a limb
 //
 // Invariants of the accumulator between mixed additions (checked against the formulas in madd28 below):
-//   X tight, value < 9.5 p;   Y loose, value < 9.5 p;   ZZ, ZZZ tight, value < 1.1 p      (inf: all limbs zero)
+//   X tight, value < 9.5 p;   Y tight, value < 8 p (1.5 p after the first addition);   ZZ, ZZZ tight, value < 1.1 p   (inf: all limbs zero)
 // Derivation (p / 2^392 = 1 / 2521):  P = U2 + 32p - X < 33.1p,  PP = P^2 < (33.1^2 / 2521 + 1) p = 1.44p,  PPP, Q < 1.02p,
 //   R = S2 + 32p - Y < 33.5p,  R^2 < 1.45p,  s = PPP + 2Q < 3.1p (limbs < 3 * 2^28),  X3 = R^2 + 8p - s < 9.5p,
-//   Q - X3 + 32p < 33.1p (limbs < 2^30),  t1 = R (Q - X3) < 1.45p,  t2 = Y1 PPP < 1.01p,  Y3 = t1 + 8p - t2 < 9.5p (limbs < 2^30).
+//   Q - X3 + 32p < 33.1p (limbs < 2^30),  32p - Y1 < 32p (limbs < 2^29),  Y3 = [R (Q - X3) + (32p - Y1) PPP] / 2^392 + p < 1.5p.
 // Everything outside the accumulation kernel keeps the 12 x 32-bit form; conversion happens once per table entry (at
 // precomputation) and once per bucket part (at the store).
 #pragma once
@@ -40,6 +40,16 @@ __device__ __forceinline__ Fp28 mul28(const Fp28 &a, const Fp28 &b) {
     mont_mul28_asm(r.l, a.l, b.l);
     __builtin_amdgcn_sched_barrier(0);
     (void)&mont_mul28_holder<0>;
+    return r;
+}
+// a*b + c*d with one reduction (both products into the same column accumulators): the limb bounds of the two groups must keep
+// 14 * (2^(Ea+Eb) + 2^(Ec+Ed) + 2^56) below 2^64, e.g. 28+30 and 29+28; output tight, value < (a*b + c*d) / 2^392 + p
+__device__ __forceinline__ Fp28 mul28x2(const Fp28 &a, const Fp28 &b, const Fp28 &c, const Fp28 &d) {
+    Fp28 r;
+    __builtin_amdgcn_sched_barrier(0);
+    mont_mul28x2_asm(r.l, a.l, b.l, c.l, d.l);
+    __builtin_amdgcn_sched_barrier(0);
+    (void)&mont_mul28x2_holder<0>;
     return r;
 }
 // a + K - b, limb by limb (see the header for which K goes with which b)
@@ -131,22 +141,21 @@ __device__ __forceinline__ XYZZ<Fp> xyzz28_to_fp(const XYZZ28 &a) {
 __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool negate) {
     if (is_inf28(q)) return true;
     Fp28 qy = negate ? neg28(FP28_K8_L1, q.y) : q.y;                     // loose, < 8p
-    if (is_inf28(acc)) { acc.X = q.x; acc.Y = qy; acc.ZZ = fp28_const(FP28_ONE); acc.ZZZ = acc.ZZ; return true; }
+    if (is_inf28(acc)) { acc.X = q.x; acc.Y = negate ? norm28(qy) : qy; acc.ZZ = fp28_const(FP28_ONE); acc.ZZZ = acc.ZZ; return true; }
     Fp28 U2 = mul28(q.x, acc.ZZ);
     Fp28 S2 = mul28(qy, acc.ZZZ);
     Fp28 P = norm28(sub28(U2, FP28_K32_L1, acc.X));                      // X1 tight, < 16p  ->  P tight, < 33.1p
     Fp28 PP = mul28(P, P);                                               // < 1.44p
     if (fp28_product_is_zero(PP)) return false;
-    Fp28 R = norm28(sub28(S2, FP28_K32_L4, acc.Y));                      // Y1 loose, < 16p  ->  R tight, < 33.1p
+    Fp28 R = norm28(sub28(S2, FP28_K32_L1, acc.Y));                      // Y1 tight, < 16p  ->  R tight, < 33.5p
     Fp28 PPP = mul28(P, PP);
     Fp28 Q = mul28(acc.X, PP);
     Fp28 s;                                                              // PPP + 2Q: limbs < 3 * 2^28, value < 4p
 #pragma unroll
     for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
     Fp28 X3 = norm28(sub28(mul28(R, R), FP28_K8_L4, s));                 // tight, < 9.5p
-    Fp28 t1 = mul28(R, sub28(Q, FP28_K32_L1, X3));                       // (Q - X3) loose, < 33.1p
-    Fp28 t2 = mul28(acc.Y, PPP);
-    acc.Y = sub28(t1, FP28_K8_L1, t2);                                   // loose, < 9.5p
+    // Y3 = R (Q - X3) - Y1 PPP = R (Q - X3) + (32p - Y1) PPP: one dual product, one reduction; limb bounds 28+30 and 29+28
+    acc.Y = mul28x2(R, sub28(Q, FP28_K32_L1, X3), neg28(FP28_K32_L1, acc.Y), PPP);      // tight, < 1.5p
     acc.X = X3;
     acc.ZZ = mul28(acc.ZZ, PP);
     acc.ZZZ = mul28(acc.ZZZ, PPP);
