@@ -58,8 +58,8 @@ int vsp_synchronize(vsp_ctx *ctx);
 double vsp_get_stat(vsp_ctx *ctx, const char *name);
 void vsp_stats_reset(vsp_ctx *ctx);
 /* tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
- * the H multi-exponentiation before the witness ones), "msm_fp28" (1: G1 bases are kept a second time on 14 x 28-bit limbs for the
- * accumulation kernel -- 112 bytes per point on top of the 96; 0 before an upload / precomputation leaves that copy out and the
+ * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
+ * accumulation kernel -- 112 (G1) / 224 (G2) bytes per point on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
  * 12 x 32-bit kernel runs) */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
 

@@ -188,7 +188,9 @@ def gen28():
     R1 = (1 << 392) % P381
     consts = "\n".join([arr("FP28_P", p28), arr("FP28_ONE", limbs28(R1)), arr("FP28_R2", limbs28(R1 * R1 % P381)),
                         arr("FP28_K8_L1", redundant(8, 1)), arr("FP28_K8_L4", redundant(8, 4)),
-                        arr("FP28_K32_L1", redundant(32, 1)), arr("FP28_K32_L4", redundant(32, 4))])
+                        arr("FP28_K32_L1", redundant(32, 1)), arr("FP28_K32_L4", redundant(32, 4)),
+                        arr("FP28_K64_L1", redundant(64, 1)), arr("FP28_K64_L4", redundant(64, 4)),
+                        arr("FP28_2P", limbs28(2 * P381)), arr("FP28_3P", limbs28(3 * P381))])
     outs = ", ".join(f'"={{v{2 * N28 + i}}}"(r[{i}])' for i in range(N28))
     inps = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N28)] + [f'"{{v{N28 + i}}}"(b[{i}])' for i in range(N28)])
     # dual variant

@@ -191,13 +191,15 @@ int vsp_d2h(vsp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
 }
 
 // ---- bases ------------------------------------------------------------------------------------
-// G1: the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off
+// the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off
 static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     if (b->d28) { hipFree(b->d28); b->d28 = nullptr; }
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
     void *t28 = nullptr;
-    if (!want || hipMalloc(&t28, count * 112) != hipSuccess) { hipGetLastError(); return; }
-    if (msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28) == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) b->d28 = t28;
+    const size_t row = b->group == 1 ? 112 : 224;
+    if (!want || hipMalloc(&t28, count * row) != hipSuccess) { hipGetLastError(); return; }
+    int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28);
+    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) b->d28 = t28;
     else { hipFree(t28); hipGetLastError(); }
 }
 static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n) {
@@ -216,7 +218,7 @@ static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_o
         }
         rc = group == 1 ? bases_to_mont_g1(ctx, src, (G1Affine *)b->d, n) : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n);
         if (rc != VSP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(b->d); delete b; return nullptr; }
-        if (group == 1 && n >= 1024) build_table28(ctx, b, n);       // best effort: without it the 12 x 32-bit kernel runs
+        if (n >= 1024) build_table28(ctx, b, n);       // best effort: without it the 12 x 32-bit kernel runs
     }
     return b;
 }
@@ -247,7 +249,8 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
     if (bases->group == 1)
         return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
                              bases->d28 ? (const char *)bases->d28 + first * 112 : nullptr);
-    return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr);
+    return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
+                         bases->d28 ? (const char *)bases->d28 + first * 224 : nullptr);
 }
 }  // namespace vsp
 extern "C" {
@@ -275,7 +278,7 @@ int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) {
     VSP_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(b->d);
     b->d = table; b->pre_c = window_bits;
-    if (b->group == 1) build_table28(ctx, b, (size_t)W * b->n);
+    build_table28(ctx, b, (size_t)W * b->n);
     return VSP_OK;
 }
 

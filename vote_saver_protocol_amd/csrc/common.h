@@ -43,7 +43,7 @@ struct MsmGeom {
     uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
 };
 // reference to the precomputed window multiples of resident bases
-struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), G1 only, or null
+struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
@@ -93,7 +93,7 @@ struct vsp_bases {
     void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
                             // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
     unsigned pre_c = 0;
-    void *d28 = nullptr;    // G1: the same array (or table) once more as Affine28 (14 x 28-bit limbs, fp28.h) for the accumulation kernel
+    void *d28 = nullptr;    // the same array (or table) once more on 14 x 28-bit limbs (fp28.h: 112-byte rows G1, 224-byte rows G2) for the accumulation kernel
 };
 
 // math::evaluation_domain<Fr>: the basic radix-2 domain (step = 0, m = big_m = 2^log_big) or the step radix-2 domain
@@ -174,8 +174,10 @@ int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr
 int msm_g1_precompute(vsp_ctx *ctx, G1Affine *table, size_t n, unsigned c);
 int msm_g2_precompute(vsp_ctx *ctx, G2Affine *table, size_t n, unsigned c);
 int msm_g1_table28(vsp_ctx *ctx, const G1Affine *table, size_t count, void *d_out /* count x 112 bytes */);
+int msm_g2_table28(vsp_ctx *ctx, const G2Affine *table, size_t count, void *d_out /* count x 224 bytes */);
 int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
-int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre);
+int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre,
+                  const void *plain_table28 = nullptr);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);

@@ -27,6 +27,8 @@ struct Fp28 { uint32_t l[14]; };                       // 56 bytes (no over-alig
 struct alignas(16) Affine28 { Fp28 x, y; };          // 112 bytes = 7 x 16
 static_assert(sizeof(Fp28) == 56 && sizeof(Affine28) == 112, "table rows are 112 bytes");
 struct XYZZ28 { Fp28 X, Y, ZZ, ZZZ; };
+struct alignas(16) Affine28x2 { Fp28 xc0, xc1, yc0, yc1; };      // 224 bytes: one G2 point of the 28-bit table
+static_assert(sizeof(Affine28x2) == 224, "G2 table rows are 224 bytes");
 
 #if defined(__HIP_DEVICE_COMPILE__)        // the product routine exists in the device pass only; kernels guard their bodies alike
 __device__ __forceinline__ Fp28 fp28_zero() { Fp28 r; for (int i = 0; i < 14; i++) r.l[i] = 0; return r; }
@@ -159,6 +161,89 @@ __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool nega
     acc.X = X3;
     acc.ZZ = mul28(acc.ZZ, PP);
     acc.ZZZ = mul28(acc.ZZZ, PPP);
+    return true;
+}
+// ================================================================ G2: Fp2 over the 28-bit form, one Fp2 value per lane pair
+// (even lane c0, odd lane c1, as Fp2L in field.h).  A product is ONE dual product per lane (schoolbook, one reduction):
+//   even lane  a0 b0 + a1 (K - b1),   odd lane  a0 b1 + a1 b0;     a square is one single product per lane:
+//   even lane  (a0 + a1)(a0 + K - a1),   odd lane  a0 * 2 a1.
+// Every component obeys the bounds of the G1 path; the places where they differ are annotated.
+
+__device__ __forceinline__ Fp28 partner28(const Fp28 &a) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xF, 0xF, false);
+    return r;
+}
+__device__ __forceinline__ Fp28 select28(bool c, const Fp28 &a, const Fp28 &b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+// own components a, b of two Fp2 values -> own component of their product.  KB negates the partner's b (it must dominate it);
+// limb bounds: E(a) + E(b) <= 59 and E(a) + E(KB - b) <= 59 over both lanes
+__device__ __forceinline__ Fp28 mulF2(const Fp28 &a, const Fp28 &b, const uint32_t (&KB)[14]) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    Fp28 ap = partner28(a), bp = partner28(b);
+    Fp28 u = select28(hi, ap, a), w = select28(hi, a, ap);
+    Fp28 nb = select28(hi, bp, neg28(KB, bp));
+    return mul28x2(u, b, w, nb);                 // even: a0 b0 + a1 (K - b1)     odd: a0 b1 + a1 b0
+}
+// KA dominates the partner component of a
+__device__ __forceinline__ Fp28 sqrF2(const Fp28 &a, const uint32_t (&KA)[14]) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    Fp28 ap = partner28(a), sum, dbl;
+#pragma unroll
+    for (int i = 0; i < 14; i++) { sum.l[i] = a.l[i] + ap.l[i]; dbl.l[i] = 2u * a.l[i]; }
+    Fp28 x = select28(hi, ap, sum);              // odd: a0            even: a0 + a1
+    Fp28 y = select28(hi, dbl, sub28(a, KA, ap));// odd: 2 a1          even: a0 + K - a1
+    return mul28(x, y);
+}
+// a tight product output below 4p is congruent to zero exactly when it is 0, p, 2p or 3p; the Fp2 value is zero when both are
+__device__ __forceinline__ bool fp28_small_is_zero(const Fp28 &a) {
+    return fp28_all_zero(a) || fp28_equals(a, FP28_P) || fp28_equals(a, FP28_2P) || fp28_equals(a, FP28_3P);
+}
+__device__ __forceinline__ bool pair_all28(bool c) {
+    int f = c ? 1 : 0;
+    return (f & __builtin_amdgcn_update_dpp(0, f, 0xB1, 0xF, 0xF, false)) != 0;
+}
+struct AffineHalf28 { Fp28 x, y; };              // this lane's components of an affine G2 point
+struct XYZZHalf28 { Fp28 X, Y, ZZ, ZZZ; };
+__device__ __forceinline__ XYZZHalf28 xyzz_half28_inf() { XYZZHalf28 r; r.X = r.Y = r.ZZ = r.ZZZ = fp28_zero(); return r; }
+
+// acc += q over Fp2 (madd-2008-s as madd28 above).  Component bounds where they differ from the G1 path:
+//   PP, RR = squares: even lane (a0 + a1)(a0 + 64p - a1) with a < 33.5p -> < (67 * 97.5 / 2521 + 1) p = 3.6p  (zero test: 0, p, 2p, 3p)
+//   X3 = RR + 8p - (PPP + 2Q) < 11.7p (tight);   Y3 = t1 + 8p - t2 < 9.4p, limbs < 2^30 (R subtracts it with FP28_K32_L4)
+// Returns false in the equal-x case (both lanes alike).
+__device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q, bool negate) {
+    const bool hi = (threadIdx.x & 1) != 0;
+    if (pair_all28(fp28_all_zero(q.x) && fp28_all_zero(q.y))) return true;                    // infinity
+    Fp28 qy = negate ? neg28(FP28_K8_L1, q.y) : q.y;                                           // limbs < 2^29, < 8p
+    if (pair_all28(fp28_all_zero(acc.ZZ))) {
+        acc.X = q.x; acc.Y = qy;
+        acc.ZZ = hi ? fp28_zero() : fp28_const(FP28_ONE); acc.ZZZ = acc.ZZ;
+        return true;
+    }
+    Fp28 U2 = mulF2(q.x, acc.ZZ, FP28_K8_L1);                                                  // ZZ tight < 4p
+    Fp28 S2 = mulF2(qy, acc.ZZZ, FP28_K8_L1);                                                  // 29+28, 29+29
+    Fp28 P = norm28(sub28(U2, FP28_K32_L1, acc.X));                                            // X tight < 16p -> P tight < 33.1p
+    Fp28 PP = sqrF2(P, FP28_K64_L1);                                                           // 29 + 30; < 3.6p
+    if (pair_all28(fp28_small_is_zero(PP))) return false;
+    Fp28 R = norm28(sub28(S2, FP28_K32_L4, acc.Y));                                            // Y limbs < 2^30, < 16p -> R tight < 33.5p
+    Fp28 PPP = mulF2(P, PP, FP28_K8_L1);                                                       // PP tight < 4p
+    Fp28 Q = mulF2(acc.X, PP, FP28_K8_L1);
+    Fp28 s;
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];                             // limbs < 3 * 2^28, < 4p
+    Fp28 X3 = norm28(sub28(sqrF2(R, FP28_K64_L1), FP28_K8_L4, s));                             // tight < 11.7p
+    Fp28 D = sub28(Q, FP28_K32_L1, X3);                                                        // limbs < 2^30, < 33.1p
+    Fp28 t1 = mulF2(R, D, FP28_K64_L4);                                                        // 28+30, 28+31 (64p - D: limbs < 5 * 2^28)
+    Fp28 t2 = mulF2(acc.Y, PPP, FP28_K8_L1);                                                   // 30+28, 30+29
+    acc.Y = sub28(t1, FP28_K8_L1, t2);                                                         // limbs < 2^30, < 9.4p
+    acc.X = X3;
+    acc.ZZ = mulF2(acc.ZZ, PP, FP28_K8_L1);
+    acc.ZZZ = mulF2(acc.ZZZ, PPP, FP28_K8_L1);
     return true;
 }
 #endif
