@@ -16,8 +16,11 @@ POOL1 = int(os.environ.get("POOL1", "30000")); POOL2 = int(os.environ.get("POOL2
 pool1 = cref.g1_batch_mul_gen(rand_fr_array(POOL1, seed=1000 + seed))
 pool2 = cref.g2_batch_mul_gen(rand_fr_array(POOL2, seed=2000 + seed))
 t0 = time.time(); it = 0; stats = {}
+last = time.time()
 while time.time() - t0 < budget:
     it += 1
+    if time.time() - last > 60:
+        print("... %d cases, %.0f s" % (it, time.time() - t0), flush=True); last = time.time()
     group = 1 if rng.random() < 0.75 else 2
     pool = pool1 if group == 1 else pool2
     n = int(np.exp(rng.uniform(0, np.log(len(pool))))) or 1

@@ -13,8 +13,11 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = v.Context(0)
 t0 = time.time(); it = 0; kinds = {"basic_radix2": 0, "step_radix2": 0}
+last = time.time()
 while time.time() - t0 < budget:
     it += 1
+    if time.time() - last > 60:
+        print("... %d cases, %.0f s" % (it, time.time() - t0), flush=True); last = time.time()
     nc = int(np.exp(rng.uniform(np.log(2), np.log(float(os.environ.get("MAX_NC", "5000"))))))
     ni = int(rng.integers(0, min(30, nc) + 1))
     s = int(rng.integers(1, 1 << 30))
