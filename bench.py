@@ -2,18 +2,25 @@
 """bench.py -- headline benchmark of the MI355X-native Groth16 prover hot path.
 
 Metric (BASELINE.json): G1 MSM points/sec at 2^20 (config[1]: 2^20-point BLS12-381 G1 Pippenger MSM, random
-scalars/points, bit-exact vs multiexp), whole job, inputs resident in HBM.  One "step" = one full MSM of the
-rank's resident 2^20-point shard (sort + bucket accumulation + bucket reduction + host Horner), then -- for
-N > 1 -- the exchange step of the sharded MSM: an RCCL all-gather of the 144-byte Jacobian partial sums and a
-local fold.  Per-GPU work is fixed as N grows ("weak": N ranks = one 2^20*N-point MSM).
+scalars/points, bit-exact vs multiexp), whole job, inputs resident in HBM, PLAIN bases (no precomputed table).  One
+"step" = one full MSM of the rank's resident shard (sort + bucket accumulation + bucket reduction + host Horner), then
+-- when launched by torch.distributed.run -- the exchange step of the sharded MSM: an RCCL all-gather of the 144-byte
+(G1) / 288-byte (G2) Jacobian partial sums and a local fold.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                       # headline: 2^20 G1 points per GPU ("weak")
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    ... bench.py --gpus N --scaling strong --total-log-n 26 --group g1    # BASELINE config 5: ONE 2^26-point problem, rank g holds chunk g
+    ... bench.py --gpus N --scaling strong --total-log-n 24 --group g2
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation, k_accum) with HIP
-events recorded on the launch stream inside the timed region; `cpu_baseline` times the oracle's serial BDLO12
-(the reference algorithm, 1 thread like the reference build) on the same inputs -- a reported baseline only.
-Nothing here reads /root/reference.
+Without --scaling strong the per-GPU work is fixed (2^20 points per rank, "weak"); the default run additionally measures
+BASELINE config 5 (2^26 G1 + 2^24 G2 points split over the N ranks) as `extras.config5`, so the driver's N = 1, 2, 4, 8 lines carry
+the strong-scaling curve of that fixed problem next to the headline.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation, k_accum28) with HIP events recorded on
+the launch stream, from a leg with ONE multi-exponentiation in flight (so nothing else shares the GPU with the kernel; the
+pipelined average is reported beside it); `cpu_baseline` times the oracle's serial BDLO12 (the reference algorithm, 1 thread like
+the reference build) on the same inputs, `cpu_baseline_all_cores` the same split in chunks over every host core (the `chunks`
+argument of multiexp) -- reported baselines only.  Nothing here reads /root/reference.
 """
 import argparse
 import json
@@ -28,7 +35,10 @@ sys.path.insert(0, ROOT)
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-BYTES_PER_PAIR_G1 = 128        # 96 B affine base + 32 B scalar
+BYTES_PER_PAIR = {1: 128, 2: 224}   # affine base (96 / 192 B) + 32 B scalar
+MADS_PER_ADD = {1: 8 * 392 + 588, 2: 2 * (8 * 588 + 2 * 392)}   # v_mad_u64_u32 per mixed addition (G2: two lanes per point)
+VALU_PEAK_MADS = 1.46e9 * 64 * 256  # measured v_mad_u64_u32 issue peak (profiles/r1_ubench_valu.txt): wave-instr/s/CU x lanes x CUs
+PMC_FILES = ("r2_pmc_hbm_traffic.json", "r1_h_pmc_hbm_traffic.json")   # newest first; see profiles/README.md
 
 
 def rand_fr(n, seed):
@@ -167,18 +177,96 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     return out
 
 
+
+def shard_bounds(total, world, rank):
+    """contiguous point chunk of rank `rank`: [lo, hi)"""
+    return rank * total // world, (rank + 1) * total // world
+
+
+def dot_mod_r_device(torch, k64, s4):
+    """sum_i k_i * s_i mod r for 64-bit k (int64 bit patterns, [n]) and 256-bit s ([n,4] int64 limbs), on the device: both are cut in
+    16-bit pieces, the 64 piece-by-piece sums stay below 2^58 for n <= 2^26, python ints put them together.  Checker arithmetic."""
+    kp = [(k64 >> (16 * i)) & 0xFFFF for i in range(4)]
+    total = 0
+    for j in range(16):
+        sj = (s4[:, j // 4] >> (16 * (j % 4))) & 0xFFFF
+        for i in range(4):
+            total += int((kp[i] * sj).sum().item()) << (16 * (i + j))
+    return total % R_MOD
+
+
+class ShardedMsm:
+    """One MSM problem of `total` points of group 1 / 2 split by contiguous chunk over the ranks; every rank builds and keeps only
+    its chunk (bases k_i * generator with 64-bit k_i -- full-size curve points; the small k only makes the checker's sum cheap --
+    and uniform 254-bit scalars, both generated on the device)."""
+
+    def __init__(self, ctx, v, torch, dev, group, total, world, rank, seed):
+        self.ctx, self.v, self.group, self.total, self.world = ctx, v, group, total, world
+        lo, hi = shard_bounds(total, world, rank)
+        self.n = n = hi - lo
+        g = torch.Generator(device=dev); g.manual_seed(seed * 1000003 + rank)
+        k64 = torch.randint(-(1 << 63), (1 << 63) - 1, (n,), dtype=torch.int64, device=dev, generator=g)
+        self.d_s = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=dev, generator=g)
+        self.d_s[:, 3] &= 0x3FFFFFFFFFFFFFFF                       # < 2^254 < r: canonical
+        k4 = torch.zeros((n, 4), dtype=torch.int64, device=dev); k4[:, 0] = k64
+        torch.cuda.synchronize()
+        d_b = v.fixed_base_mul(ctx, k4, n, group)
+        del k4
+        self.bases = ctx.bases_from_device(d_b, n, group)
+        ctx.dfree(d_b)
+        self.e_local = dot_mod_r_device(torch, k64, self.d_s)
+        del k64
+
+    def free(self):
+        self.bases.free(); self.d_s = None
+
+
+def run_sharded(problem, steps, warmup, exchange, barrier, depth):
+    """`steps` MSMs over the rank's chunk + exchange, `depth` in flight; returns (seconds for `steps`, last folded result)"""
+    sl = (1, 2, 4, 5)[:max(1, min(4, depth))]
+    D = len(sl)
+
+    def go(k_steps):
+        res = None
+        if D == 1:
+            for _ in range(k_steps):
+                res = exchange(problem.bases.msm_jacobian(problem.d_s), problem.group)
+            return res
+        for k in range(min(D - 1, k_steps)):
+            problem.bases.msm_launch(sl[k % D], problem.d_s)
+        for k in range(k_steps):
+            if k + D - 1 < k_steps:
+                problem.bases.msm_launch(sl[(k + D - 1) % D], problem.d_s)
+            res = exchange(problem.bases.msm_finish_jacobian(sl[k % D]), problem.group)
+        return res
+
+    if warmup:
+        go(warmup)
+    barrier(); t0 = time.perf_counter()
+    res = go(steps)
+    barrier()
+    return time.perf_counter() - t0, res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20, help="log2 of the points per GPU (BASELINE config: 20)")
+    ap.add_argument("--log-n", type=int, default=20, help="weak scaling: log2 of the points per GPU (BASELINE config 2: 20)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="strong: ONE problem of 2^total-log-n points of --group split over the ranks (BASELINE config 5)")
+    ap.add_argument("--total-log-n", type=int, default=0, help="strong scaling: log2 of the whole problem (default 26 for g1, 24 for g2)")
+    ap.add_argument("--group", choices=("g1", "g2"), default="g1")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (2^26 G1 + 2^24 G2 over the ranks) of the default run")
+    ap.add_argument("--config5-log-g1", type=int, default=26)
+    ap.add_argument("--config5-log-g2", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary NTT / G2 measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary NTT / G2 / resident-key measurements")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--pipeline-depth", type=int, default=3, help="MSMs in flight (work slots with their own streams)")
     ap.add_argument("--no-pipeline", action="store_true", help="blocking MSM calls (one in flight): for clean per-kernel profiles")
-    ap.add_argument("--no-precompute", action="store_true", help="do not precompute the window multiples of the resident bases")
+    ap.add_argument("--precompute", action="store_true", help="headline over a resident key with window multiples (16x table) instead of plain bases")
     ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
@@ -214,112 +302,165 @@ def main():
         ctx.set_option("msm_split", int(os.environ["VSP_MSM_SPLIT"]))      # experiment knob: points per bucket part
     if args.prove_h_first >= 0:
         ctx.set_option("prove_h_first", args.prove_h_first)
+    depth = 1 if args.no_pipeline else args.pipeline_depth
 
-    n = 1 << args.log_n
-    # ---- synthetic inputs (SURVEY.md 8(d) cfg 2): bases k_i * G built on the GPU, uniform scalars; all resident
-    ks = rand_fr(n, seed=1000 + rank)
-    ss = rand_fr(n, seed=2000 + rank)
-    d_k = torch.from_numpy(ks.view(np.int64)).to(dev)
-    d_s = torch.from_numpy(ss.view(np.int64)).to(dev)
-    torch.cuda.synchronize()
-    d_bases_canon = v.fixed_base_mul(ctx, d_k, n, 1)
-    bases = ctx.bases_from_device(d_bases_canon, n, 1)
-    del d_k
-    if args.log_n > 21:
-        args.no_precompute = True      # measured: the precomputed table pays up to ~2^21 points per GPU (fixed tails); equal beyond
-    if not args.no_precompute:
-        # once per resident key: 2^(16 w) * P for the 16 windows (16x the bases' memory); every MSM then shares one bucket set
-        t_pre = time.perf_counter()
-        bases.precompute(16)
-        precompute_s = time.perf_counter() - t_pre
-    else:
-        precompute_s = None
+    rec_dev = {g: torch.zeros(18 * g, dtype=torch.int64, device=dev) for g in (1, 2)}
+    all_dev = {g: torch.zeros(18 * g * world, dtype=torch.int64, device=dev) for g in (1, 2)}
 
-    rec_dev = torch.zeros(18, dtype=torch.int64, device=dev)
-    all_dev = torch.zeros(18 * world, dtype=torch.int64, device=dev)
-
-    def exchange(rec):
-        if use_dist:                                        # exchange step: 144-byte Jacobian record per rank
-            rec_dev.copy_(torch.from_numpy(rec.view(np.int64)))
-            dist.all_gather_into_tensor(all_dev, rec_dev)
-            recs = all_dev.cpu().numpy().view(np.uint64).reshape(world, 18)
+    def exchange(rec, group=1):
+        w = 18 * group
+        if use_dist:                                        # exchange step: one Jacobian record per rank (144 B G1 / 288 B G2)
+            rec_dev[group].copy_(torch.from_numpy(rec.view(np.int64)))
+            dist.all_gather_into_tensor(all_dev[group], rec_dev[group])
+            recs = all_dev[group].cpu().numpy().view(np.uint64).reshape(world, w)
         else:
-            recs = rec.reshape(1, 18)
-        return v.fold_jacobian(ctx, recs, 1)                # local fold + affine normalisation
+            recs = rec.reshape(1, w)
+        return v.fold_jacobian(ctx, recs, group)            # local fold + affine normalisation
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(k_steps):
-        """k_steps full MSMs, software-pipelined over work slots with their own streams (default three deep; measured 1: 5.38 ms, 2: 4.02, 3: 3.72, 4: 3.78): the sort and
-        bucket accumulation of step k+1 overlap the latency-bound bucket reduction and host Horner of step k."""
-        if args.no_pipeline:
-            for _ in range(k_steps):
-                res = exchange(bases.msm_jacobian(d_s))
-            return res
-        res = None
-        sl = (1, 2, 4, 5)[:max(1, min(4, args.pipeline_depth))]   # work slots with streams of equal priority
-        D = len(sl)
-        for k in range(min(D - 1, k_steps)):
-            bases.msm_launch(sl[k % D], d_s)
-        for k in range(k_steps):
-            if k + D - 1 < k_steps:
-                bases.msm_launch(sl[(k + D - 1) % D], d_s)
-            res = exchange(bases.msm_finish_jacobian(sl[k % D]))
-        return res
-
-    if args.warmup:
-        result = run_steps(args.warmup)
-    ctx.stats_reset()
-    barrier()
-    t0 = time.perf_counter()
-    result = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    accum_ms = ctx.stat("msm_accum_ms")
-    accum_launches = ctx.stat("msm_accum_launches")
-    main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
-    # transparency: the same pipelined loop over PLAIN resident bases (no precomputed window multiples), not part of `value`
-    plain_ms = None
-    if not args.no_precompute and not args.no_extras:
-        plain = ctx.bases_from_device(d_bases_canon, n, 1)
-        keep = bases
-        bases = plain
-        run_steps(2)
-        barrier(); tp = time.perf_counter()
-        run_steps(max(4, args.steps // 2))
-        barrier(); plain_ms = (time.perf_counter() - tp) / max(4, args.steps // 2) * 1e3
-        bases = keep
-        plain.free()
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def allmax(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # ---- untimed verification: sum over all ranks of (sum_i k_i s_i) * G must equal the folded result
-    e_local = int(sum((to_ints(ks) * to_ints(ss)).tolist()) % R_MOD)
-    e_dev = torch.from_numpy(limbs(e_local, 4).view(np.int64)).to(dev)
-    if use_dist:
+    def gather_e(e_local):
+        e_dev = torch.from_numpy(limbs(e_local, 4).view(np.int64)).to(dev)
+        if not use_dist:
+            return e_local % R_MOD
         e_all = torch.zeros(4 * world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(e_all, e_dev)
-        e_rows = e_all.cpu().numpy().view(np.uint64).reshape(world, 4)
-    else:
-        e_rows = limbs(e_local, 4).reshape(1, 4)
-    verified = None
-    cpu_baseline = None
-    extras = {}
+        rows = e_all.cpu().numpy().view(np.uint64).reshape(world, 4)
+        return sum(int(x) for x in to_ints(rows).tolist()) % R_MOD
+
+    cref = o = gens = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import cref                                          # checker / CPU baseline only
         import bls12_381 as o
-        e_tot = sum(int(x) for x in to_ints(e_rows).tolist()) % R_MOD
-        expect = cref.g1_mul(np.array(o.g1_to_limbs(o.G1.gen), dtype=np.uint64), limbs(e_tot, 4))
-        verified = bool(np.array_equal(result, expect))
+        gens = {1: np.array(o.g1_to_limbs(o.G1.gen), dtype=np.uint64), 2: np.array(o.g2_to_limbs(o.G2.gen), dtype=np.uint64)}
+
+    def expected_point(group, e_tot):                        # rank 0: (sum_i k_i s_i) * generator by the oracle's scalar multiplication
+        return (cref.g1_mul if group == 1 else cref.g2_mul)(gens[group], limbs(e_tot, 4))
+
+    def accum_stats():
+        ms, launches = ctx.stat("msm_accum_ms"), ctx.stat("msm_accum_launches")
+        return (ms / launches) if launches else float("nan")
+
+    def roofline_of(group, n_points, windows, excl_ms, excl_step_ms, pipe_ms):
+        """HBM line (the contract's) and the v_mad_u64_u32 issue line (the bound that applies) for one accumulation launch"""
+        bytes_alg = n_points * BYTES_PER_PAIR[group]
+        achieved = bytes_alg / (excl_ms * 1e-3) / 1e9
+        traffic, src = None, None
+        if group == 1 and n_points == 1 << 20:
+            key = "k_accum_G1_2p20_precomputed" if args.precompute else "k_accum_G1_2p20_plain"
+            for f in PMC_FILES:
+                try:
+                    with open(os.path.join(ROOT, "profiles", f)) as fh:
+                        j = json.load(fh)
+                    use = key if key in j else "k_accum_G1_2p20"
+                    traffic = j[use]["traffic_bytes_per_launch"]; src = "profiles/" + f + ":" + use
+                    break
+                except Exception:
+                    continue
+        mads = n_points * windows * MADS_PER_ADD[group]
+        rl = {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation on 14 x 28-bit limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+              "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
+              "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": excl_ms, "ms_per_step_same_mode": excl_step_ms,
+              "avg_launch_ms_pipelined": pipe_ms,
+              "note": "avg_launch_ms: HIP events around the kernel with ONE multi-exponentiation in flight (nothing else on the GPU), so it is <= "
+                      "ms_per_step_same_mode; avg_launch_ms_pipelined is the same bracket inside the timed region, where neighbouring steps' kernels share "
+                      "the GPU.  The kernel is integer-issue bound (about 160 Montgomery products per point), not HBM bound: see roofline_valu.  traffic is "
+                      "not measurable in-process (PMC passes need rocprofv3): it is read from traffic_source"}
+        rv = {"bound": "v_mad_u64_u32 issue", "kernel": rl["kernel"], "achieved": mads / (excl_ms * 1e-3) / 1e12, "peak": VALU_PEAK_MADS / 1e12,
+              "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads / (excl_ms * 1e-3) / VALU_PEAK_MADS, "mads_per_mixed_addition": MADS_PER_ADD[group],
+              "mixed_additions_per_launch": n_points * windows, "peak_source": "profiles/r1_ubench_valu.txt (tools/ubench_valu.hip, measured on MI355X)"}
+        return rl, rv
+
+    extras = {}
+    cpu_baseline = cpu_all = None
+    verified = None
+
+    # =============================================================== strong scaling: ONE problem split over the ranks (BASELINE config 5)
+    if args.scaling == "strong":
+        group = 1 if args.group == "g1" else 2
+        lg_total = args.total_log_n or (26 if group == 1 else 24)
+        total = 1 << lg_total
+        prob = ShardedMsm(ctx, v, torch, dev, group, total, world, rank, seed=77 + group)
+        ctx.stats_reset()
+        elapsed, result = run_sharded(prob, args.steps, args.warmup, exchange, barrier, depth)
+        elapsed = allmax(elapsed)
+        pipe_ms = accum_stats()
+        main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
+        ctx.stats_reset()
+        ex_steps = max(2, args.steps // 4)
+        ex_elapsed, _ = run_sharded(prob, ex_steps, 1, exchange, barrier, 1)
+        ex_elapsed = allmax(ex_elapsed)
+        excl_ms = accum_stats()
+        e_tot = gather_e(prob.e_local)
+        if rank == 0:
+            verified = bool(np.array_equal(result, expected_point(group, e_tot)))
+        rl, rv = roofline_of(group, prob.n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms)
+        out = {"metric": f"{args.group.upper()} MSM points/sec, one 2^{lg_total}-point problem sharded over the GPUs (BASELINE config 5)",
+               "value": total * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": f"one 2^{lg_total}-point BLS12-381 {args.group.upper()} Pippenger MSM, plain bases k_i*G (64-bit k_i), uniform 254-bit scalars, "
+                                      f"resident in HBM; rank g holds the contiguous chunk g of {world}; one RCCL all-gather of {144 * group}-byte Jacobian records + local fold per MSM",
+                          "total_points": total, "points_per_gpu": prob.n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth},
+               "verified_bit_exact": verified, "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3, "roofline": rl, "roofline_valu": rv,
+               "cpu_baseline": None}
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        prob.free(); ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
+
+    # =============================================================== headline (weak): 2^log_n G1 points per GPU, plain bases
+    n = 1 << args.log_n
+    # synthetic inputs (SURVEY.md 8(d) cfg 2): bases k_i * G built on the GPU, uniform scalars; all resident
+    ks = rand_fr(n, seed=1000 + rank)
+    ss = rand_fr(n, seed=2000 + rank)
+    d_k = torch.from_numpy(ks.view(np.int64)).to(dev)
+    d_s = torch.from_numpy(ss.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    d_bases_canon = v.fixed_base_mul(ctx, d_k, n, 1)
+    del d_k
+
+    class Head:                                              # the run_sharded interface over the headline inputs
+        group = 1
+    head = Head(); head.d_s = d_s; head.n = n
+    head.bases = ctx.bases_from_device(d_bases_canon, n, 1)
+    precompute_s = None
+    if args.precompute:
+        t_pre = time.perf_counter(); head.bases.precompute(16); precompute_s = time.perf_counter() - t_pre
+
+    ctx.stats_reset()
+    elapsed, result = run_sharded(head, args.steps, args.warmup, exchange, barrier, depth)
+    elapsed = allmax(elapsed)
+    pipe_ms = accum_stats()
+    main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
+    # the same MSM with ONE in flight: latency of a single multi-exponentiation and the exclusive duration of its accumulation kernel
+    ctx.stats_reset()
+    ex_steps = max(4, args.steps // 2)
+    ex_elapsed, _ = run_sharded(head, ex_steps, 1, exchange, barrier, 1)
+    ex_elapsed = allmax(ex_elapsed)
+    excl_ms = accum_stats()
+
+    # ---- untimed verification: sum over all ranks of (sum_i k_i s_i) * G must equal the folded result
+    e_tot = gather_e(int(sum((to_ints(ks) * to_ints(ss)).tolist()) % R_MOD))
+    if rank == 0:
+        verified = bool(np.array_equal(result, expected_point(1, e_tot)))
 
         if world == 1 and not args.no_cpu_baseline:
-            # reference algorithm on the host: serial BDLO12 (c = 16 at 2^20), same bases and scalars, 1 thread
+            # reference algorithm on the host: serial BDLO12 (c = 16 at 2^20), same bases and scalars, 1 thread -- then the same work
+            # cut in `cores` chunks (multiexp's chunks argument) on every host core
             host_b = np.zeros((n, 12), np.uint64)
             ctx.d2h(host_b, d_bases_canon)
             m = min(n, 1 << 20)
@@ -330,6 +471,32 @@ def main():
             cpu_baseline = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
                             "sample": f"one {m}-point G1 MSM (serial BDLO12 restatement, oracle/vsp_ref.c), {dt:.1f} s",
                             "matches_gpu_result": ok}
+            from concurrent.futures import ThreadPoolExecutor
+            cores = len(os.sched_getaffinity(0))
+            cuts = [shard_bounds(m, cores, i) for i in range(cores)]
+            tc = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:             # the C call releases the GIL: one chunk per core
+                parts = list(ex.map(lambda ab: cref.msm_g1(host_b[ab[0]:ab[1]], ss[ab[0]:ab[1]]), cuts))
+            acc = None
+            for q in parts:
+                acc = q if acc is None else np.array(o.g1_to_limbs(o.G1.add(o.g1_from_limbs(acc), o.g1_from_limbs(q))), dtype=np.uint64)
+            dta = time.perf_counter() - tc
+            cpu_all = {"value": m / dta, "unit": "points/s", "cores": cores, "kind": "port",
+                       "sample": f"the same {m}-point G1 MSM in {cores} chunks, one thread per host core, partial sums added ({dta:.2f} s)",
+                       "matches_gpu_result": bool(np.array_equal(acc, result)) if m == n else None}
+            del host_b
+
+        if world == 1 and not args.no_extras and not args.precompute:
+            # a resident proving key may keep the window multiples 2^(16 w) * P (16x the memory, built once): every MSM over it shares one bucket set
+            pre = Head(); pre.d_s = d_s; pre.n = n
+            pre.bases = ctx.bases_from_device(d_bases_canon, n, 1)
+            t_pre = time.perf_counter(); pre.bases.precompute(16); pre_s = time.perf_counter() - t_pre
+            ctx.stats_reset()
+            k2 = max(4, args.steps // 2)
+            el2, res2 = run_sharded(pre, k2, 2, exchange, barrier, depth)
+            extras["resident_key_window_multiples"] = {"ms_per_step": el2 / k2 * 1e3, "points_per_s": n * k2 / el2, "table_memory_factor": 16, "build_once_s": pre_s,
+                                                       "k_accum28_avg_ms_pipelined": accum_stats(), "same_result": bool(np.array_equal(res2, result))}
+            pre.bases.free()
 
         if world == 1 and not args.no_extras:
             # secondary numbers (not the headline): BASELINE config 3 (2^22 NTT) and a 2^18 G2 MSM
@@ -345,7 +512,6 @@ def main():
             dtn = (time.perf_counter() - tn) / reps
             extras["ntt_2p22_ms"] = dtn * 1e3
             extras["ntt_2p22_elements_per_s"] = (1 << lg) / dtn
-            extras["ntt_2p22_algorithmic_GBs"] = (1 << lg) * 64 / dtn / 1e9
             # algorithmic bytes = 64 B per element for the whole transform (one ideal read + write); the kernel makes
             # `passes` round trips through HBM, each reading and writing every element once
             npass = int(ctx.stat("ntt_passes"))
@@ -354,30 +520,24 @@ def main():
                                            "actual_bytes_moved": npass * (1 << lg) * 64, "per_pass_GBs": (1 << lg) * 64 / (dtn / npass) / 1e9,
                                            "note": "integer-VALU bound: 11 Fr products per element; see DESIGN.md 3.2 for the measured split"}
             del a
-            # G2: 2^18 points, and 2^21 = the per-GPU shard of BASELINE config 5 (2^24 G2 points over 8 GPUs); verified through the
-            # discrete-log identity sum_i s_i (k_i G2) = (sum_i k_i s_i) G2 against the oracle's scalar multiplication
-            g2_gen = np.array(o.g2_to_limbs(o.G2.gen), dtype=np.uint64)
-            for lg2 in (18, 21):
-                n2 = 1 << lg2
-                k2, s2 = rand_fr(n2, 11), rand_fr(n2, 12)
-                d_k2 = torch.from_numpy(k2.view(np.int64)).to(dev)
-                d_b2 = v.fixed_base_mul(ctx, d_k2, n2, 2)
-                b2 = ctx.bases_from_device(d_b2, n2, 2)
-                ctx.dfree(d_b2)
-                d_s2 = torch.from_numpy(s2.view(np.int64)).to(dev)
-                res2, _ = b2.msm(d_s2)
-                tg = time.perf_counter()
-                for _ in range(3):
-                    b2.msm(d_s2)
-                dtg = (time.perf_counter() - tg) / 3
-                e2 = int(sum((to_ints(k2) * to_ints(s2)).tolist()) % R_MOD)
-                extras[f"g2_msm_2p{lg2}_ms"] = dtg * 1e3
-                extras[f"g2_msm_2p{lg2}_points_per_s"] = n2 / dtg
-                extras[f"g2_msm_2p{lg2}_verified"] = bool(np.array_equal(res2, cref.g2_mul(g2_gen, limbs(e2, 4))))
-                b2.free()
-                del d_k2, d_s2
-
-        if world == 1 and not args.no_extras:
+            n2 = 1 << 18
+            k2, s2 = rand_fr(n2, 11), rand_fr(n2, 12)
+            d_k2 = torch.from_numpy(k2.view(np.int64)).to(dev)
+            d_b2 = v.fixed_base_mul(ctx, d_k2, n2, 2)
+            b2 = ctx.bases_from_device(d_b2, n2, 2)
+            ctx.dfree(d_b2)
+            d_s2 = torch.from_numpy(s2.view(np.int64)).to(dev)
+            res2, _ = b2.msm(d_s2)
+            tg = time.perf_counter()
+            for _ in range(3):
+                b2.msm(d_s2)
+            dtg = (time.perf_counter() - tg) / 3
+            e2 = int(sum((to_ints(k2) * to_ints(s2)).tolist()) % R_MOD)
+            extras["g2_msm_2p18_ms"] = dtg * 1e3
+            extras["g2_msm_2p18_points_per_s"] = n2 / dtg
+            extras["g2_msm_2p18_verified"] = bool(np.array_equal(res2, expected_point(2, e2)))
+            b2.free()
+            del d_k2, d_s2
             # host-buffer entry point (vsp_msm_g1): bases and scalars cross PCIe on every call -- never `value`
             host_b = np.zeros((n, 12), np.uint64)
             ctx.d2h(host_b, d_bases_canon)
@@ -387,32 +547,38 @@ def main():
             dth = time.perf_counter() - th
             extras["msm_host_buffers_2p20_ms"] = dth * 1e3
             extras["msm_host_buffers_2p20_points_per_s"] = n / dth
-            extras["msm_host_buffers_matches"] = bool(np.array_equal(res_h, result)) if world == 1 else None
+            extras["msm_host_buffers_matches"] = bool(np.array_equal(res_h, result))
             del host_b
 
         if world == 1 and not args.no_prove:
-            extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=not args.no_precompute))
-            extras.update(bench_prove_step_domain(ctx, v, cref, o, precompute=not args.no_precompute))
+            extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=True))
+            extras.update(bench_prove_step_domain(ctx, v, cref, o, precompute=True))
 
     ctx.dfree(d_bases_canon)
-    total_points = n * world * args.steps
-    value = total_points / elapsed
-    accum_avg_s = (accum_ms / accum_launches) * 1e-3 if accum_launches else float("nan")
-    precomputed = bool(not args.no_precompute)       # (log_n > 21 switches precomputation off above)
-    mads_per_add = (8 * 392 + 588) if True else 0      # 28-bit-limb accumulation (plain and precomputed G1 bases): 8 products + 1 dual product
-    achieved = n * BYTES_PER_PAIR_G1 / accum_avg_s / 1e9 if accum_launches else float("nan")
-    # HBM-side traffic of the dominant kernel cannot be read inside this process (PMC passes need rocprofv3): it is taken
-    # from the committed summary of the same command, profiles/r1_h_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes)
-    traffic = None
-    try:
-        if args.log_n == 20:
-            with open(os.path.join(ROOT, "profiles", "r1_h_pmc_hbm_traffic.json")) as f:
-                traffic = json.load(f)["k_accum_G1_2p20"]["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    head.bases.free()
+    del d_s
+
+    # =============================================================== BASELINE config 5 in the same run: 2^26 G1 + 2^24 G2 over the ranks
+    if not args.no_config5 and not (world == 1 and args.no_extras):
+        c5 = {"scaling": "strong", "n_gpus": world, "msms_in_flight": depth}
+        for group, lg in ((1, args.config5_log_g1), (2, args.config5_log_g2)):
+            prob = ShardedMsm(ctx, v, torch, dev, group, 1 << lg, world, rank, seed=55 + group)
+            ctx.stats_reset()
+            k5 = 3
+            el5, res5 = run_sharded(prob, k5, 1, exchange, barrier, depth)
+            el5 = allmax(el5)
+            e5 = gather_e(prob.e_local)
+            tag = "g1" if group == 1 else "g2"
+            c5[tag] = {"total_log_n": lg, "points_per_gpu": prob.n, "ms_per_msm": el5 / k5 * 1e3, "points_per_s": (1 << lg) * k5 / el5,
+                       "k_accum28_avg_ms_pipelined": accum_stats(), "window_bits": int(ctx.stat("msm_window_bits")),
+                       "verified": bool(np.array_equal(res5, expected_point(group, e5))) if rank == 0 else None}
+            prob.free()
+        extras["config5"] = c5
+
+    rl, rv = roofline_of(1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms)
     out = {
         "metric": "G1 MSM points/sec at 2^20 (Groth16 prover hot path)",
-        "value": value,
+        "value": n * world * args.steps / elapsed,
         "unit": "points/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -421,32 +587,21 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32",          # 32-bit limbs, 32x32->64-bit multiply-add: exact integer Montgomery arithmetic (381-bit Fp, 255-bit Fr)
+        "dtype": "u32",          # 32-bit registers: 28-bit limbs, 32x32->64-bit multiply-add: exact integer Montgomery arithmetic (381-bit Fp, 255-bit Fr)
         "data": "synthetic",
-        "config": {"workload": f"2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU, bases k_i*G, uniform scalars, "
-                               f"resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
-                               "RCCL all-gather of Jacobian partial sums + fold",
-                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w,
-                   "bases_precomputed_window_multiples": not args.no_precompute, "bases_memory_factor": 1 if args.no_precompute else main_w,
-                   "precompute_once_s": precompute_s,
-                   "plain_bases_ms_per_step": plain_ms, "plain_bases_points_per_s": (n * world / (plain_ms * 1e-3)) if plain_ms else None},
+        "config": {"workload": (f"2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU, " +
+                                ("resident key WITH the 16x table of window multiples, " if args.precompute else "PLAIN bases k_i*G (no precomputed table), ") +
+                                f"uniform scalars, bases and scalars resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
+                                "RCCL all-gather of Jacobian partial sums + fold"),
+                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth,
+                   "bases_precomputed_window_multiples": bool(args.precompute), "bases_memory_factor": 16 if args.precompute else 1,
+                   "precompute_once_s": precompute_s},
         "verified_bit_exact": verified,
-        "roofline": {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation, 28-bit limbs)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic,
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_PAIR_G1, "avg_launch_ms": accum_avg_s * 1e3,
-                     "note": "integer-VALU bound (about 160 Montgomery products per point), not HBM bound; launch time is measured while the "
-                             "neighbouring step's kernels share the GPU (three MSMs in flight); traffic = 2*FETCH_SIZE + WRITE_SIZE from "
-                             "profiles/r1_h_pmc_hbm_traffic.json: every base is gathered once per window (16 rows of 112 B from the 28-bit-limb table), see DESIGN.md"},
-        # the bound that actually applies: 32x32->64-bit multiply-add issue.  One mixed addition = 10 Montgomery products; with
-        # the accumulation runs on 14 x 28-bit limbs: 2 * 14 * 14 = 392 v_mad_u64_u32 per product, carry-free, and one dual product
-        # a*b + c*d with a single reduction (588) -- 3724 per mixed addition.  peak = measured v_mad_u64_u32 issue rate
-        # (profiles/r1_ubench_valu.txt: 1.46 G wave-instructions/s/CU x 64 lanes x 256 CUs).  Same launch time as above.
-        "roofline_valu": {"bound": "v_mad_u64_u32 issue", "kernel": "k_accum28 (bucket accumulation, 14 x 28-bit limbs)",
-                          "achieved": n * main_w * mads_per_add / accum_avg_s / 1e12 if accum_launches else None,
-                          "peak": 1.46e9 * 64 * 256 / 1e12, "unit": "T v_mad_u64_u32 lane-ops/s",
-                          "frac": (n * main_w * mads_per_add / accum_avg_s) / (1.46e9 * 64 * 256) if accum_launches else None},
+        "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3,
+        "roofline": rl,
+        "roofline_valu": rv,
         "cpu_baseline": cpu_baseline,
+        "cpu_baseline_all_cores": cpu_all,
     }
     if extras:
         out["extras"] = extras
@@ -457,7 +612,6 @@ def main():
                                 "single_context_proofs_per_s": extras["prove_2p20_proofs_per_s"], "single_proof_latency_ms": extras["prove_2p20_ms"]}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    bases.free()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

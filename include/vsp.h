@@ -39,7 +39,8 @@ typedef struct vsp_pk vsp_pk;           /* device-resident Groth16 proving key *
 
 enum {
     VSP_OK = 0,
-    VSP_ERR_ARG = -1,        /* null pointer, size out of range, scalar/coordinate layout violated */
+    VSP_ERR_ARG = -1,        /* null pointer, size out of range, scalar/coordinate layout violated: a scalar >= r (reported when the
+                              * multi-exponentiation / proof finishes), a base coordinate >= p or a base off the curve (at upload) */
     VSP_ERR_HIP = -2,        /* a HIP runtime call failed; vsp_last_error() has the text */
     VSP_ERR_NOMEM = -3,
     VSP_ERR_UNSUPPORTED = -4 /* e.g. log_m > 28 */
@@ -57,9 +58,12 @@ int vsp_synchronize(vsp_ctx *ctx);
  * accumulation kernel, summed since the last vsp_stats_reset), "msm_accum_launches", "msm_window_bits". */
 double vsp_get_stat(vsp_ctx *ctx, const char *name);
 void vsp_stats_reset(vsp_ctx *ctx);
-/* tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
+/* options: "bases_check_curve" (default 1: uploads verify y^2 = x^3 + b for every point; coordinates < p are always checked),
+ * "msm_census_sync" (1: every multi-exponentiation waits for its own 0/1 census before planning; default 0: a slot plans from the
+ * count it saw for the previous vector of the same length -- the count steers window size and part length, never the result);
+ * tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
  * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
- * accumulation kernel -- 112 (G1) / 224 (G2) bytes per point on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
+ * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
  * 12 x 32-bit kernel runs) */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
 
@@ -68,6 +72,11 @@ void *vsp_dmalloc(vsp_ctx *ctx, size_t bytes);
 void vsp_dfree(vsp_ctx *ctx, void *dptr);
 int vsp_h2d(vsp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int vsp_d2h(vsp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Page-lock / release caller memory: host buffers the library copies from on every call (the witness of vsp_groth16_prove) then
+ * travel by asynchronous DMA instead of the runtime's staged pageable path.  The reference keeps its witness in a std::vector
+ * (common.hpp:1110-1128); registering that storage once costs nothing per proof. */
+int vsp_host_register(vsp_ctx *ctx, void *ptr, size_t bytes);
+int vsp_host_unregister(vsp_ctx *ctx, void *ptr);
 
 /* ---- multi-scalar multiplication: algebra::multiexp<multiexp_method_BDLO12> (a1), ------------
  *      multiexp_with_mixed_addition (a2: zero scalars are skipped, equal-to-one scalars are summed

@@ -19,6 +19,9 @@ template <> struct point_traits<G1pt> {
     static G1pt zero() { G1pt p; memset(&p, 0, sizeof p); p.inf = true; return p; }
 };
 }
+// stand-ins for knowledge_commitment<T1, T2> and knowledge_commitment_vector<T1, T2> (members as upstream names them)
+struct KC { G1pt g; G1pt h; };
+struct KCVec { std::vector<std::size_t> indices; std::vector<KC> values; std::size_t domain_size_; };
 int main() {
     G1pt g{{{0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL}},
            {{0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL}}, false};
@@ -27,6 +30,16 @@ int main() {
     try {
         G1pt r = vsp::multiexp<vsp::policies::multiexp_method_BDLO12>(bases.begin(), bases.end(), scalars.begin(), scalars.end(), 1);
         std::printf("2G.x[0] = %016llx\n", (unsigned long long)r.x.l[0]);
+        // kc_multiexp_with_mixed_addition over a sparse pair vector: entries 1, 2, 4 of a domain of 6, index window [1, 5)
+        KCVec kv{{0, 1, 2, 4, 5}, {KC{g, g}, KC{g, r}, KC{r, g}, KC{g, g}, KC{g, g}}, 6};
+        std::vector<Fr4> ksc{Fr4{{1, 0, 0, 0}}, Fr4{{0, 0, 0, 0}}, Fr4{{5, 0, 0, 0}}, Fr4{{2, 0, 0, 0}}};     // scalars for indices 1, 2, 3, 4
+        KC kc = vsp::kc_multiexp_with_mixed_addition<vsp::policies::multiexp_method_BDLO12>(kv, 1, 5, ksc.begin(), ksc.end(), 1);
+        // g-half: 1*G + 0*2G + 2*G = 3G;  h-half: 1*2G + 0*G + 2*G = 4G
+        std::vector<G1pt> b3{g}; std::vector<Fr4> s3{Fr4{{3, 0, 0, 0}}}, s4{Fr4{{4, 0, 0, 0}}};
+        G1pt g3 = vsp::multiexp(b3.begin(), b3.end(), s3.begin(), s3.end()), g4 = vsp::multiexp(b3.begin(), b3.end(), s4.begin(), s4.end());
+        bool kc_ok = !memcmp(&kc.g.x, &g3.x, 48) && !memcmp(&kc.g.y, &g3.y, 48) && !memcmp(&kc.h.x, &g4.x, 48) && !memcmp(&kc.h.y, &g4.y, 48);
+        std::printf("kc_multiexp %s\n", kc_ok ? "ok" : "MISMATCH");
+        if (!kc_ok) return 1;
         bool ok = true;
         for (std::size_t min_size : {5, 8, 11, 70}) {          // 5 -> 5 (step 4+1), 8 -> 8 (basic), 11 -> 12 (step 8+4), 70 -> 72 (step 64+8)
             auto dom = vsp::make_evaluation_domain<Fr4>(min_size);

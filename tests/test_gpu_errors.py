@@ -60,3 +60,115 @@ def test_status_codes_and_messages(ctx, cref):
     # the context still works afterwards
     b = cref.g1_batch_mul_gen(rand_fr_array(10, 2)); s = rand_fr_array(10, 3)
     assert np.array_equal(v.multiexp(ctx, b, s, 1), cref.msm_g1(b, s))
+
+
+def test_boundary_validation_of_scalars_and_bases(ctx, cref):
+    """include/vsp.h: VSP_ERR_ARG for a scalar >= r, a base coordinate >= p, a base off the curve (the reference's field types
+    cannot hold such values; a raw-limb boundary must refuse them instead of returning another point)."""
+    import bls12_381 as o
+    from conftest import L, g1_limbs, g2_limbs
+    n = 300
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, 5)); ss = rand_fr_array(n, 6)
+    good = cref.msm_g1(bases, ss)
+    # --- scalars: r itself, r + 5, 2^256 - 1, at the first, a middle and the last position
+    for bad_val in (o.R, o.R + 5, (1 << 256) - 1):
+        for pos in (0, 137, n - 1):
+            s2 = ss.copy(); s2[pos] = L(bad_val, 4)
+            with pytest.raises(v.VspError, match="canonical"):
+                v.multiexp(ctx, bases, s2, 1)
+    s2 = ss.copy(); s2[3] = L(o.R - 1, 4)                                      # the largest canonical value is fine
+    assert np.array_equal(v.multiexp(ctx, bases, s2, 1), cref.msm_g1(bases, s2))
+    big = 5000                                                                 # above the census threshold, resident + pipelined form
+    bb = cref.g1_batch_mul_gen(rand_fr_array(big, 7)); sb = rand_fr_array(big, 8); sb[4321] = L(o.R, 4)
+    B = ctx.upload_bases(bb, 1); d_s = ctx.to_device(sb)
+    with pytest.raises(v.VspError, match="canonical"):
+        B.msm(d_s)
+    B.msm_launch(2, d_s)
+    with pytest.raises(v.VspError, match="canonical"):
+        B.msm_finish_jacobian(2)
+    sb[4321] = 0; ctx.h2d(d_s, sb)
+    got, _ = B.msm(d_s)                                                        # the slot recovers
+    assert np.array_equal(got, cref.msm_g1(bb, sb, mixed=True))
+    ctx.dfree(d_s); B.free()
+    # --- bases: coordinate >= p
+    b2 = bases.copy(); b2[7, :6] = L(o.P, 6)
+    with pytest.raises(v.VspError, match="canonical"):
+        ctx.upload_bases(b2, 1)
+    b2 = bases.copy(); b2[n - 1, 6:] = L(o.P + 1, 6)
+    with pytest.raises(v.VspError, match="canonical"):
+        v.multiexp(ctx, b2, ss, 1)
+    # --- bases: not on the curve (x of one point, y of another)
+    b3 = bases.copy(); b3[11, 6:] = bases[12, 6:]
+    with pytest.raises(v.VspError, match="curve"):
+        ctx.upload_bases(b3, 1)
+    ctx.set_option("bases_check_curve", 0)                                     # the check is an option; the coordinate check is not
+    try:
+        ctx.upload_bases(b3, 1).free()
+        with pytest.raises(v.VspError, match="canonical"):
+            ctx.upload_bases(b2, 1)
+    finally:
+        ctx.set_option("bases_check_curve", 1)
+    g2b = cref.g2_batch_mul_gen(rand_fr_array(40, 9))
+    g2bad = g2b.copy(); g2bad[5, 12:18] = g2b[6, 12:18]
+    with pytest.raises(v.VspError, match="curve"):
+        ctx.upload_bases(g2bad, 2)
+    g2bad = g2b.copy(); g2bad[0, 6:12] = L(o.P, 6)
+    with pytest.raises(v.VspError, match="canonical"):
+        ctx.upload_bases(g2bad, 2)
+    inf = bases.copy(); inf[3] = 0                                             # infinity stays legal
+    assert np.array_equal(v.multiexp(ctx, inf, ss, 1), cref.msm_g1(inf, ss))
+    assert np.array_equal(v.multiexp(ctx, bases, ss, 1), good)
+
+
+def test_prover_refuses_non_canonical_inputs_and_recovers(ctx, cref):
+    import bls12_381 as o
+    from conftest import L, fr_array
+    gen = o.splitmix64(9)
+    cs, wit = cref.R1CS.synth(600, 4, 9)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    dcs = v.R1CS(ctx, 600, 4, cs.num_vars, *cs.export())
+    kp = v.Keypair(ctx, dcs, tox)
+    r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
+    ok = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
+    with pytest.raises(v.VspError, match="canonical"):
+        v.groth16_prove(ctx, dcs, kp.pk, wit, L(o.R, 4), s)
+    w2 = wit.copy(); w2[77] = L(o.R + 1, 4)
+    with pytest.raises(v.VspError, match="canonical"):                         # reported when the multi-exponentiations finish; all slots drained
+        v.groth16_prove(ctx, dcs, kp.pk, w2, r, s)
+    again = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
+    assert all(np.array_equal(a, b) for a, b in zip(ok[:3], again[:3])) and ok[3] == again[3]
+    A, B, Cm = cs.export()
+    co = A[2].copy(); co[0] = L(o.R, 4)
+    with pytest.raises(v.VspError, match="canonical"):
+        v.R1CS(ctx, 600, 4, cs.num_vars, (A[0], A[1], co), B, Cm)
+    kp.free(); dcs.free(); cs.free()
+
+
+def test_fp28_kernel_known_answer_check_and_fallback(cref):
+    """The 28-bit-limb accumulation kernels are checked THROUGH k_accum28 against the generic kernel when a context builds its first
+    table; a failed check switches the context to the generic kernel, results unchanged."""
+    c = v.Context(0)
+    try:
+        n = 3000
+        bases = cref.g1_batch_mul_gen(rand_fr_array(n, 21)); ss = rand_fr_array(n, 22)
+        b2 = cref.g2_batch_mul_gen(rand_fr_array(1100, 23))
+        exp = cref.msm_g1(bases, ss)
+        assert np.array_equal(v.multiexp(c, bases, ss, 1), exp)
+        assert c.stat("msm_fp28_selfcheck_g1") == 1.0
+        B2 = c.upload_bases(b2, 2)
+        assert c.stat("msm_fp28_selfcheck_g2") == 1.0
+        B2.free()
+    finally:
+        c.close()
+    c = v.Context(0)
+    try:
+        c.set_option("msm_fp28_selfcheck_fault", 1)                            # test hook: the comparison reports a mismatch
+        assert np.array_equal(v.multiexp(c, bases, ss, 1), exp)                # generic 12 x 32-bit kernel took over
+        assert c.stat("msm_fp28_selfcheck_g1") == -1.0 and "known-answer" in c.last_error()
+        B = c.upload_bases(bases, 1).precompute(0)
+        d_s = c.to_device(ss)
+        got, _ = B.msm(d_s)
+        assert np.array_equal(got, exp)
+        c.dfree(d_s); B.free()
+    finally:
+        c.close()

@@ -382,3 +382,60 @@ def test_msm_randomized_configurations(ctx, cref):
         finally:
             ctx.set_option("msm_window_bits", 0)
             B.free()
+
+
+def _dlog_identity(ks, ss):
+    """sum_i k_i s_i mod r through numpy object arrays (8 M terms in a few seconds)"""
+    from conftest import fr_ints_fast
+    import numpy as np
+    k = np.array(fr_ints_fast(ks), dtype=object); s = np.array(fr_ints_fast(ss), dtype=object)
+    return int((k * s).sum() % o.R)
+
+
+def test_msm_g1_2p23_config5_shard_plain_bases(ctx, cref):
+    """BASELINE config 5, the per-GPU share of the G1 half: 2^26 points over 8 GPUs = 2^23 points per rank, PLAIN resident bases
+    (no window-multiple table).  sum_i s_i (k_i G) = (sum_i k_i s_i) G on the whole shard, a 2^15-point slice bit for bit against
+    the C oracle's BDLO12, and the Jacobian record the rank would send folds to the same point."""
+    n = 1 << 23
+    ks = rand_fr_array(n, seed=101); ss = rand_fr_array(n, seed=102)
+    ss[1000:3000] = 0; ss[2000:3000, 0] = 1
+    d_k = ctx.to_device(ks); d_s = ctx.to_device(ss)
+    d_b = v.fixed_base_mul(ctx, d_k, n, 1)
+    ctx.dfree(d_k)
+    B = ctx.bases_from_device(d_b, n, 1)
+    try:
+        got, inf = B.msm(d_s)
+        e = _dlog_identity(ks, ss)
+        assert not inf and np.array_equal(got, cref.g1_mul(g1_limbs(o.G1.gen), L(e, 4)))
+        assert ctx.stat("msm_bucket_sets") == ctx.stat("msm_windows")            # plain bases: one bucket set per window
+        rec = B.msm_jacobian(d_s)
+        assert np.array_equal(v.fold_jacobian(ctx, rec[None], 1), got)
+        m, at = 1 << 15, (1 << 22) + 12345
+        host_b = np.zeros((m, 12), np.uint64); ctx.d2h(host_b, d_b + 96 * at)
+        part, _ = B.msm(d_s + 32 * at, n=m, first=at)
+        assert np.array_equal(part, cref.msm_g1(host_b, ss[at:at + m]))
+    finally:
+        B.free(); ctx.dfree(d_b); ctx.dfree(d_s)
+
+
+def test_msm_g2_2p21_config5_shard_plain_bases(ctx, cref):
+    """BASELINE config 5, the per-GPU share of the G2 half: 2^24 points over 8 GPUs = 2^21 per rank, plain bases; the identity on
+    the whole shard, a 2^12-point slice against the C oracle, and the 288-byte Jacobian record."""
+    n = 1 << 21
+    ks = rand_fr_array(n, seed=111); ss = rand_fr_array(n, seed=112)
+    d_k = ctx.to_device(ks); d_s = ctx.to_device(ss)
+    d_b = v.fixed_base_mul(ctx, d_k, n, 2)
+    ctx.dfree(d_k)
+    B = ctx.bases_from_device(d_b, n, 2)
+    try:
+        got, inf = B.msm(d_s)
+        e = _dlog_identity(ks, ss)
+        assert not inf and np.array_equal(got, cref.g2_mul(g2_limbs(o.G2.gen), L(e, 4)))
+        rec = B.msm_jacobian(d_s)
+        assert rec.shape == (36,) and np.array_equal(v.fold_jacobian(ctx, rec[None], 2), got)
+        m, at = 1 << 12, (1 << 20) + 777
+        host_b = np.zeros((m, 24), np.uint64); ctx.d2h(host_b, d_b + 192 * at)
+        part, _ = B.msm(d_s + 32 * at, n=m, first=at)
+        assert np.array_equal(part, cref.msm_g2(host_b, ss[at:at + m]))
+    finally:
+        B.free(); ctx.dfree(d_b); ctx.dfree(d_s)

@@ -127,3 +127,35 @@ def test_generator_bit_exact_vs_oracle(ctx, cref, nc, ni, precompute):
     ea, eb, ec = ref.prove(wit, r, s)
     assert np.array_equal(pa, ea) and np.array_equal(pb, eb) and np.array_equal(pc, ec)
     kp.free(); dcs.free(); ref.free(); cs.free()
+
+
+def test_generate_and_prove_2p20_config4_pairing(ctx, cref):
+    """BASELINE config 4 at full size: a synthetic SAVER-shaped R1CS filling the 2^20 domain (2^20 - 32 constraints, 30 public
+    inputs, 90 % boolean wires), key generated on the GPU, proof made on the GPU -- once over the plain key and once
+    over the key with window multiples -- identical proofs, Groth16 pairing equation checked by the oracle's pairing, the SAVER
+    addend r_enc * P1 moves C by exactly that point."""
+    import pairing as pg
+    ni = 30
+    nc = (1 << 20) - ni - 2
+    gen = o.splitmix64(2020)
+    cs, wit = cref.R1CS.synth(nc, ni, 4)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
+    assert dcs.m == 1 << 20 and dcs.domain_kind == "basic_radix2"
+    r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
+    kp = v.Keypair(ctx, dcs, tox, precompute=False)
+    pa, pb, pc, proof = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
+    vk = dict(alpha_g1=o.g1_from_limbs(kp.part("alpha_g1")[0]), beta_g2=o.g2_from_limbs(kp.part("beta_g2")[0]),
+              gamma_g2=o.g2_from_limbs(kp.part("gamma_g2")[0]), delta_g2=o.g2_from_limbs(kp.part("delta_g2")[0]),
+              gamma_ABC_g1=[o.g1_from_limbs(x) for x in kp.part("gamma_ABC_g1")])
+    pub = [I(wit[i]) for i in range(ni)]
+    assert pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
+    assert np.array_equal(v.g1_decompress(proof[0:48]), pa) and np.array_equal(v.g2_decompress(proof[48:144]), pb)
+    P1 = kp.part("gamma_ABC_g1")[1]; renc = L(o.rand_fr(gen), 4)
+    _, _, pc2, _ = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s, saver_P1=P1, saver_r_enc=renc)
+    assert o.g1_from_limbs(pc2) == o.G1.add(o.g1_from_limbs(pc), o.G1.mul(o.g1_from_limbs(P1), I(renc)))
+    kp.free()
+    kp2 = v.Keypair(ctx, dcs, tox, precompute=True)                      # resident key with window multiples: the same proof
+    qa, qb, qc, proof2 = v.groth16_prove(ctx, dcs, kp2.pk, wit, r, s)
+    assert np.array_equal(qa, pa) and np.array_equal(qb, pb) and np.array_equal(qc, pc) and proof2 == proof
+    kp2.free(); dcs.free(); cs.free()

@@ -19,4 +19,5 @@ def test_cpp_shims_run(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     two_g = o.G1.mul(o.G1.gen, 2)
     assert ("2G.x[0] = %016x" % (two_g[0] & 0xFFFFFFFFFFFFFFFF)) in p.stdout
+    assert "kc_multiexp ok" in p.stdout
     assert "roundtrip ok" in p.stdout

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "vsp_dfree": (None, [_P, _P]),
     "vsp_h2d": (_I, [_P, _P, _P, _SZ]),
     "vsp_d2h": (_I, [_P, _P, _P, _SZ]),
+    "vsp_host_register": (_I, [_P, _P, _SZ]),
+    "vsp_host_unregister": (_I, [_P, _P]),
     "vsp_msm_g1": (_I, [_P, _P, _P, _SZ, _P, _P]),
     "vsp_msm_g2": (_I, [_P, _P, _P, _SZ, _P, _P]),
     "vsp_bases_upload_g1": (_P, [_P, _P, _SZ]),

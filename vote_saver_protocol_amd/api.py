@@ -105,6 +105,14 @@ class Context:
     def d2h(self, host, dptr):
         self.check(self.lib.vsp_d2h(self.h, _ptr(host), C.c_void_p(dptr), host.nbytes))
 
+    def host_register(self, arr):
+        """Page-lock a host array the library copies from on every call (the witness): its transfers become asynchronous DMA."""
+        self.check(self.lib.vsp_host_register(self.h, _ptr(arr), arr.nbytes))
+        return arr
+
+    def host_unregister(self, arr):
+        self.check(self.lib.vsp_host_unregister(self.h, _ptr(arr)))
+
     def to_device(self, host):
         host = np.ascontiguousarray(host)
         p = self.dmalloc(max(host.nbytes, 16))

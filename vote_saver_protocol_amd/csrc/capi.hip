@@ -133,7 +133,7 @@ void vsp_destroy(vsp_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch, &ctx->dom_scratch,
-                      &ctx->msm_scalars, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
+                      &ctx->msm_scalars, &ctx->val_flag, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
                       &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
     for (DevBuf *b : bufs) free_buf(*b);
     msm_free_slots(ctx);
@@ -190,18 +190,81 @@ int vsp_d2h(vsp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     return VSP_OK;
 }
 
+// page-lock caller memory (a witness vector, say) so that the copies vsp_groth16_prove / vsp_h2d queue from it are asynchronous DMA
+// instead of the runtime's staged pageable path
+int vsp_host_register(vsp_ctx *ctx, void *ptr, size_t bytes) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!ptr || !bytes) return set_error(ctx, VSP_ERR_ARG, "host_register: null pointer or zero size");
+    VSP_HIP(hipSetDevice(ctx->device));
+    VSP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return VSP_OK;
+}
+int vsp_host_unregister(vsp_ctx *ctx, void *ptr) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!ptr) return set_error(ctx, VSP_ERR_ARG, "host_unregister: null pointer");
+    VSP_HIP(hipHostUnregister(ptr));
+    return VSP_OK;
+}
+
 // ---- bases ------------------------------------------------------------------------------------
+}  // extern "C"
+// Known-answer check of the 28-bit-limb accumulation THROUGH k_accum28 itself (its products are hand-laid-out routines entered
+// with a private calling convention, which the compiler's hazard recogniser and register allocator cannot see into; field-level
+// selftests run them in another code arrangement).  Once per context and group, at the first table built: the same
+// multi-exponentiation over the first points of the new bases runs through k_accum28 and through the generic 12 x 32-bit k_accum;
+// the two affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0):
+// every later multi-exponentiation takes the generic kernel.  Returns true when the table may be used.
+static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void *t28, size_t count) {
+    const int gi = b->group - 1;
+    if (ctx->fp28_checked[gi] != 0) return ctx->fp28_checked[gi] > 0;
+    if (ctx->msm_work[0].active) return true;                 // slot 0 busy (unusual): check at the next table instead
+    const size_t n = count < 4096 ? count : 4096;
+    std::vector<uint64_t> sc(n * 4);
+    uint64_t x = 0x9E3779B97F4A7C15ULL ^ (uint64_t)b->group;
+    auto next = [&]() { x += 0x9E3779B97F4A7C15ULL; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
+    for (size_t i = 0; i < n; i++) {
+        sc[4 * i] = next(); sc[4 * i + 1] = next(); sc[4 * i + 2] = next(); sc[4 * i + 3] = next() >> 2;     // < 2^254 < r
+        if (i % 7 == 3) { sc[4 * i] &= 1; sc[4 * i + 1] = sc[4 * i + 2] = sc[4 * i + 3] = 0; }               // zeros and ones among them
+    }
+    bool same = false;
+    if (ensure(ctx, ctx->msm_scalars, n * 32) == VSP_OK &&
+        hipMemcpyAsync(ctx->msm_scalars.p, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        const Fr *ds = (const Fr *)ctx->msm_scalars.p;
+        if (b->group == 1) {
+            XYZZ<HFp> r28, rgen;
+            if (msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28) == VSP_OK && msm_g1_finish(ctx, 0, &r28) == VSP_OK &&
+                msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g1_finish(ctx, 0, &rgen) == VSP_OK) {
+                Affine<HFp> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
+                same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
+            }
+        } else {
+            XYZZ<HFp2> r28, rgen;
+            if (msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28) == VSP_OK && msm_g2_finish(ctx, 0, &r28) == VSP_OK &&
+                msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g2_finish(ctx, 0, &rgen) == VSP_OK) {
+                Affine<HFp2> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
+                same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
+            }
+        }
+    }
+    { auto it = ctx->opts.find("msm_fp28_selfcheck_fault"); if (it != ctx->opts.end() && it->second) same = false; }   // test hook: exercise the fallback
+    ctx->fp28_checked[gi] = same ? 1 : -1;
+    ctx->stats[b->group == 1 ? "msm_fp28_selfcheck_g1" : "msm_fp28_selfcheck_g2"] = same ? 1.0 : -1.0;
+    if (!same) { ctx->opts["msm_fp28"] = 0; ctx->err = "msm: the 28-bit-limb accumulation kernel failed its known-answer check; generic kernel in use"; }
+    return same;
+}
 // the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off
 static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     if (b->d28) { hipFree(b->d28); b->d28 = nullptr; }
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
     void *t28 = nullptr;
-    const size_t row = b->group == 1 ? 112 : 224;
+    const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
     if (!want || hipMalloc(&t28, count * row) != hipSuccess) { hipGetLastError(); return; }
     int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28);
-    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) b->d28 = t28;
+    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess && fp28_known_answer_check(ctx, b, t28, b->n < count ? b->n : count)) b->d28 = t28;
     else { hipFree(t28); hipGetLastError(); }
 }
+extern "C" {
 static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n) {
     if (!ctx) return nullptr;
     if (!src && n) { set_error(ctx, VSP_ERR_ARG, "bases: null pointer"); return nullptr; }
@@ -216,8 +279,19 @@ static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_o
             if (hipMemcpyAsync(b->d, src, n * esz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { set_error(ctx, VSP_ERR_HIP, "bases: H2D failed"); hipFree(b->d); delete b; return nullptr; }
             src = b->d;                      // convert in place
         }
-        rc = group == 1 ? bases_to_mont_g1(ctx, src, (G1Affine *)b->d, n) : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n);
-        if (rc != VSP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) { hipFree(b->d); delete b; return nullptr; }
+        // boundary validation (include/vsp.h): coordinates below p always; the curve equation unless option "bases_check_curve" = 0
+        long check_curve = 1; { auto it = ctx->opts.find("bases_check_curve"); if (it != ctx->opts.end()) check_curve = it->second; }
+        uint32_t h_flag = 0;
+        rc = ensure(ctx, ctx->val_flag, 16);
+        if (rc == VSP_OK && hipMemsetAsync(ctx->val_flag.p, 0, 16, ctx->stream) != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "bases: memset failed");
+        if (rc == VSP_OK)
+            rc = group == 1 ? bases_to_mont_g1(ctx, src, (G1Affine *)b->d, n, (int)check_curve, (uint32_t *)ctx->val_flag.p)
+                            : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n, (int)check_curve, (uint32_t *)ctx->val_flag.p);
+        if (rc == VSP_OK && (hipMemcpyAsync(&h_flag, ctx->val_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                             hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = set_error(ctx, VSP_ERR_HIP, "bases: conversion failed");
+        if (rc == VSP_OK && h_flag)
+            rc = set_error(ctx, VSP_ERR_ARG, (h_flag & 1u) ? "bases: a coordinate is not canonical (>= p)" : "bases: a point is not on the curve");
+        if (rc != VSP_OK) { hipFree(b->d); delete b; return nullptr; }
         if (n >= 1024) build_table28(ctx, b, n);       // best effort: without it the 12 x 32-bit kernel runs
     }
     return b;
@@ -248,9 +322,9 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
     }
     if (bases->group == 1)
         return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
-                             bases->d28 ? (const char *)bases->d28 + first * 112 : nullptr);
+                             bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28) : nullptr);
     return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
-                         bases->d28 ? (const char *)bases->d28 + first * 224 : nullptr);
+                         bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28x2) : nullptr);
 }
 }  // namespace vsp
 extern "C" {

@@ -57,6 +57,8 @@ struct MsmWork {
     void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
     hipEvent_t census_done = nullptr;
     bool census_pending = false; size_t census_n = 0; const void *census_scalars = nullptr;
+    bool check_pending = false;          // this launch's census (count + non-canonical flag) is to be read at finish
+    size_t neff_cache_n = 0, neff_cache = 0;   // count of the last census over a vector of neff_cache_n scalars
     MsmGeom g;
     size_t n = 0, n_eff = 0;
 };
@@ -81,6 +83,8 @@ struct vsp_ctx {
     int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
     bool lds_attr_set[2] = {false, false};
     vsp::DevBuf msm_scalars;
+    vsp::DevBuf val_flag;               // one word: validation result of the last bases upload
+    int fp28_checked[2] = {0, 0};       // known-answer check of the 28-bit-limb accumulation kernels, per group: 0 not yet, 1 passed, -1 failed (kernel disabled)
     // fixed-base tables (generator multiples), built lazily
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
     // prover workspaces
@@ -183,8 +187,10 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
 int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);
-int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n);
-int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n);
+void msm_drain_slots(vsp_ctx *ctx);
+// d_flag: one device word, zeroed by the caller; bit 0 = coordinate >= p, bit 1 = point off the curve (only when check_curve)
+int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);
+int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);
 int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
 int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
 int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi);

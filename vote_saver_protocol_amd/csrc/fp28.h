@@ -11,7 +11,8 @@
 //   a - b          = a + K - b limb by limb, K a multiple of p in a redundant form whose limbs dominate those of b
 //                  (FP28_K8_L1: b tight, b < 4p ... FP28_K32_L4: b loose, b < 16p); no borrow ever crosses a limb
 //
-// Invariants of the accumulator between mixed additions (checked against the formulas in madd28 below):
+// Invariants of the accumulator between mixed additions (checked mechanically by tests/test_fp28_bounds.py: an exact limb model
+// driven to these worst cases, and a worst-case propagation showing they are inductive):
 //   X tight, value < 9.5 p;   Y tight, value < 8 p (1.5 p after the first addition);   ZZ, ZZZ tight, value < 1.1 p   (inf: all limbs zero)
 // Derivation (p / 2^392 = 1 / 2521):  P = U2 + 32p - X < 33.1p,  PP = P^2 < (33.1^2 / 2521 + 1) p = 1.44p,  PPP, Q < 1.02p,
 //   R = S2 + 32p - Y < 33.5p,  R^2 < 1.45p,  s = PPP + 2Q < 3.1p (limbs < 3 * 2^28),  X3 = R^2 + 8p - s < 9.5p,
@@ -24,11 +25,13 @@
 namespace vsp {
 
 struct Fp28 { uint32_t l[14]; };                       // 56 bytes (no over-alignment: that would pad it to 64)
-struct alignas(16) Affine28 { Fp28 x, y; };          // 112 bytes = 7 x 16
-static_assert(sizeof(Fp28) == 56 && sizeof(Affine28) == 112, "table rows are 112 bytes");
+// Table rows are padded to whole 128-byte cache lines: a gathered G1 point is ONE line (112 bytes of payload), a G2 point two.
+// Unpadded 112 / 224-byte rows straddled two / three lines in 6 of 8 alignments: 273 bytes fetched per 112-byte gather (round 1 PMC).
+struct alignas(128) Affine28 { Fp28 x, y; };
+static_assert(sizeof(Fp28) == 56 && sizeof(Affine28) == 128, "G1 table rows are one 128-byte line");
 struct XYZZ28 { Fp28 X, Y, ZZ, ZZZ; };
-struct alignas(16) Affine28x2 { Fp28 xc0, xc1, yc0, yc1; };      // 224 bytes: one G2 point of the 28-bit table
-static_assert(sizeof(Affine28x2) == 224, "G2 table rows are 224 bytes");
+struct alignas(256) Affine28x2 { Fp28 xc0, xc1, yc0, yc1; };     // one G2 point of the 28-bit table: 224 bytes of payload in two lines
+static_assert(sizeof(Affine28x2) == 256, "G2 table rows are two 128-byte lines");
 
 #if defined(__HIP_DEVICE_COMPILE__)        // the product routine exists in the device pass only; kernels guard their bodies alike
 __device__ __forceinline__ Fp28 fp28_zero() { Fp28 r; for (int i = 0; i < 14; i++) r.l[i] = 0; return r; }
@@ -214,7 +217,8 @@ __device__ __forceinline__ XYZZHalf28 xyzz_half28_inf() { XYZZHalf28 r; r.X = r.
 
 // acc += q over Fp2 (madd-2008-s as madd28 above).  Component bounds where they differ from the G1 path:
 //   PP, RR = squares: even lane (a0 + a1)(a0 + 64p - a1) with a < 33.5p -> < (67 * 97.5 / 2521 + 1) p = 3.6p  (zero test: 0, p, 2p, 3p)
-//   X3 = RR + 8p - (PPP + 2Q) < 11.7p (tight);   Y3 = t1 + 8p - t2 < 9.4p, limbs < 2^30 (R subtracts it with FP28_K32_L4)
+//   X3 = RR + 8p - (PPP + 2Q) < 11.7p (tight);   Y3 = t1 + 8p - t2 < 10.4p (t1 = R D < (33.5 * 33.1 + 33.5 * 64) / 2521 p + p = 2.3p),
+//   limbs < 2^30 (R subtracts it with FP28_K32_L4).  tests/test_fp28_bounds.py propagates these worst cases mechanically.
 // Returns false in the equal-x case (both lanes alike).
 __device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q, bool negate) {
     const bool hi = (threadIdx.x & 1) != 0;
@@ -240,7 +244,7 @@ __device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q
     Fp28 D = sub28(Q, FP28_K32_L1, X3);                                                        // limbs < 2^30, < 33.1p
     Fp28 t1 = mulF2(R, D, FP28_K64_L4);                                                        // 28+30, 28+31 (64p - D: limbs < 5 * 2^28)
     Fp28 t2 = mulF2(acc.Y, PPP, FP28_K8_L1);                                                   // 30+28, 30+29
-    acc.Y = sub28(t1, FP28_K8_L1, t2);                                                         // limbs < 2^30, < 9.4p
+    acc.Y = sub28(t1, FP28_K8_L1, t2);                                                         // limbs < 2^30, < 10.4p
     acc.X = X3;
     acc.ZZ = mulF2(acc.ZZ, PP, FP28_K8_L1);
     acc.ZZZ = mulF2(acc.ZZZ, PPP, FP28_K8_L1);

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_affine_from_mont_g2(const G2Affine *in,
 }
 
 static Fr dev(const HFr &h) { Fr d; memcpy(&d, &h, sizeof(Fr)); return d; }
-static void free_dev(DevBuf &b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+// the generator's scratch holds functions of the toxic waste (powers of t, exponent vectors): zeroed before it goes back to the allocator
+static void free_dev(DevBuf &b) { if (b.p) { hipMemset(b.p, 0, b.cap); hipFree(b.p); } b.p = nullptr; b.cap = 0; }
 
 static const uint64_t G1_GEN_L[12] = {0xfb3af00adb22c6bbULL, 0x6c55e83ff97a1aefULL, 0xa14e3a3f171bac58ULL, 0xc3688c4f9774b905ULL, 0x2695638c4fa9ac0fULL, 0x17f1d3a73197d794ULL,
                                       0x0caa232946c5e7e1ULL, 0xd03cc744a2888ae4ULL, 0x00db18cb2c04b3edULL, 0xfcf5e095d5d00af6ULL, 0xa09e30ed741d8ae4ULL, 0x08b3f481e3aaa0f1ULL};

@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void k_fr_to_mont(Fr *a, size_t n) {
     if (i < n) a[i] = to_mont(a[i]);
 }
 
+// canonical Fr check on the host (4 x uint64 little-endian limbs below r)
+static bool fr_canonical(const uint64_t *k) {
+    for (int i = 3; i >= 0; i--) { if (k[i] < FrP64::MOD[i]) return true; if (k[i] > FrP64::MOD[i]) return false; }
+    return false;
+}
+
 }  // namespace vsp
 
 using namespace vsp;
@@ -50,13 +56,16 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
     for (int m = 0; m < 3; m++) {
         size_t nnz = rp[m][num_constraints];
         for (size_t e = 0; e < nnz; e++) if (ci[m][e] > num_vars) { set_error(ctx, VSP_ERR_ARG, "r1cs_upload: column out of range"); vsp_r1cs_free(ctx, cs); return nullptr; }
+        for (size_t e = 0; e < nnz; e++) if (!fr_canonical(co[m] + 4 * e)) { set_error(ctx, VSP_ERR_ARG, "r1cs_upload: a coefficient is not canonical (>= r)"); vsp_r1cs_free(ctx, cs); return nullptr; }
         bool ok = hipMalloc((void **)&cs->rp[m], (num_constraints + 1) * 4) == hipSuccess &&
                   hipMalloc((void **)&cs->ci[m], (nnz ? nnz : 1) * 4) == hipSuccess &&
                   hipMalloc(&cs->co[m], (nnz ? nnz : 1) * sizeof(Fr)) == hipSuccess;
         if (!ok) { set_error(ctx, VSP_ERR_NOMEM, "r1cs_upload: hipMalloc"); vsp_r1cs_free(ctx, cs); return nullptr; }
-        hipMemcpyAsync(cs->rp[m], rp[m], (num_constraints + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-        hipMemcpyAsync(cs->ci[m], ci[m], nnz * 4, hipMemcpyHostToDevice, ctx->stream);
-        hipMemcpyAsync(cs->co[m], co[m], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream);
+        if (hipMemcpyAsync(cs->rp[m], rp[m], (num_constraints + 1) * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(cs->ci[m], ci[m], nnz * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(cs->co[m], co[m], nnz * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            set_error(ctx, VSP_ERR_HIP, "r1cs_upload: host-to-device copy failed"); vsp_r1cs_free(ctx, cs); return nullptr;
+        }
         if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)cs->co[m], nnz);
         // column-major copy by a counting sort over the column index
         std::vector<uint32_t> colptr(num_vars + 2, 0), rows(nnz ? nnz : 1);
@@ -72,9 +81,11 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
         ok = hipMalloc((void **)&cs->cp[m], (num_vars + 2) * 4) == hipSuccess && hipMalloc((void **)&cs->ri[m], (nnz ? nnz : 1) * 4) == hipSuccess &&
              hipMalloc(&cs->cot[m], (nnz ? nnz : 1) * sizeof(Fr)) == hipSuccess;
         if (!ok) { set_error(ctx, VSP_ERR_NOMEM, "r1cs_upload: hipMalloc"); vsp_r1cs_free(ctx, cs); return nullptr; }
-        hipMemcpy(cs->cp[m], colptr.data(), (num_vars + 2) * 4, hipMemcpyHostToDevice);
-        hipMemcpy(cs->ri[m], rows.data(), nnz * 4, hipMemcpyHostToDevice);
-        hipMemcpy(cs->cot[m], cot.data(), nnz * sizeof(Fr), hipMemcpyHostToDevice);
+        if (hipMemcpy(cs->cp[m], colptr.data(), (num_vars + 2) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(cs->ri[m], rows.data(), nnz * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(cs->cot[m], cot.data(), nnz * sizeof(Fr), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error(ctx, VSP_ERR_HIP, "r1cs_upload: host-to-device copy failed"); vsp_r1cs_free(ctx, cs); return nullptr;
+        }
         if (nnz) hipLaunchKernelGGL(k_fr_to_mont, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)cs->cot[m], nnz);
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error(ctx, VSP_ERR_HIP, "r1cs_upload: sync"); vsp_r1cs_free(ctx, cs); return nullptr; }
@@ -109,11 +120,33 @@ vsp_pk *vsp_pk_create(vsp_ctx *ctx, const uint64_t alpha_g1[12], const uint64_t 
 }
 void vsp_pk_free(vsp_ctx *, vsp_pk *pk) { delete pk; }
 
+static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
+                        const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
+                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
+
 int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
                       const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
                       uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
     if (!ctx) return VSP_ERR_ARG;
     if (!cs || !pk || !witness || !r || !s) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
+    if (!fr_canonical(r) || !fr_canonical(s) || (saver_r_enc && !fr_canonical(saver_r_enc)))
+        return set_error(ctx, VSP_ERR_ARG, "prove: r, s and r_enc must be canonical (< r)");
+    int rc = prove_queued(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out);
+    if (rc != VSP_OK) {
+        // an early return leaves multi-exponentiations in flight on their own streams, still reading the witness and H vectors:
+        // wait for all of them before the caller (or the next call's workspace growth) can touch those buffers
+        std::string keep = ctx->err;
+        msm_drain_slots(ctx);
+        ctx->err = keep;
+    }
+    // the witness does not outlive the call in device memory
+    if (ctx->pr_z.p) hipMemsetAsync(ctx->pr_z.p, 0, ctx->pr_z.cap, ctx->stream);
+    return rc;
+}
+
+static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
+                        const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
+                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints;
     const size_t m = cs->dom.m;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
