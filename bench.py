@@ -151,6 +151,36 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
            f"prove_2p{log_m}_phase_ms": phases,
            f"prove_2p{log_m}_two_contexts_ms_per_proof": dt2 * 1e3, f"prove_2p{log_m}_two_contexts_proofs_per_s": 1.0 / dt2,
            f"prove_2p{log_m}_two_contexts_same_proof": bool(same)}
+    # the reference's vote phase around the same proof (common.hpp:1131-1145): encrypt<elgamal_verifiable> (ciphertext of the 25
+    # message blocks on the host while the GPU proves, proof with the SAVER addend) + rerandomize; verified by the oracle's pairing
+    try:
+        import saver as sv
+        nmsg = 25
+        rnd = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(3 * nmsg + 2)], dtype=np.uint64)
+        gabc_l = np.ascontiguousarray(gamma_abc)
+        delta_g1, gamma_g1 = kp.part("delta_g1")[0], kp.part("gamma_g1")[0]
+        pk_w, _, _ = v.saver_generate_keypair(ctx, rnd, gabc_l, delta_g1, gamma_g1, nmsg)
+        t0 = time.perf_counter(); spk = v.SaverPublicKey(ctx, pk_w, gabc_l[:nmsg + 1], nmsg); load_s = time.perf_counter() - t0
+        r_enc = limbs(o.rand_fr(gen), 4)
+        rnd3 = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(3)], dtype=np.uint64)
+        wit_pinned = ctx.host_register(np.ascontiguousarray(wit))
+        v.saver_encrypt(ctx, spk, dcs, pk, wit[:nmsg], wit_pinned, r_enc, r, s_)
+        t_enc = t_rer = 0.0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ct, abc, _ = v.saver_encrypt(ctx, spk, dcs, pk, wit[:nmsg], wit_pinned, r_enc, r, s_)
+            t1 = time.perf_counter()
+            ct2, abc2, _ = v.saver_rerandomize(ctx, spk, delta_g2, rnd3, ct, abc)
+            t_enc += t1 - t0; t_rer += time.perf_counter() - t1
+        ctx.host_unregister(wit_pinned)
+        pkd = sv.pk_from_words(pk_w, nmsg)
+        okv = sv.verify_encryption(pkd, vk, [o.g1_from_limbs(x) for x in ct2], (o.g1_from_limbs(abc2[0]), o.g2_from_limbs(abc2[1]), o.g1_from_limbs(abc2[2])), pub[nmsg:])
+        out.update({f"vote_phase_2p{log_m}_encrypt_ms": t_enc / reps * 1e3, f"vote_phase_2p{log_m}_rerandomize_ms": t_rer / reps * 1e3,
+                    f"vote_phase_2p{log_m}_ms": (t_enc + t_rer) / reps * 1e3, f"vote_phase_2p{log_m}_msg_size": nmsg,
+                    f"vote_phase_2p{log_m}_pk_load_once_s": load_s, f"vote_phase_2p{log_m}_verify_encryption": bool(okv)})
+        spk.free()
+    except Exception as e:                         # secondary measurement: never take the bench line down
+        out[f"vote_phase_2p{log_m}_error"] = repr(e)
     kp.free(); dcs.free(); cs.free()
     # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
     lg_s = 14

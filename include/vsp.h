@@ -206,10 +206,46 @@ typedef struct vsp_keypair vsp_keypair;
 vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64_t toxic[20], int precompute);
 const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp);
 /* Key components as canonical affine points (host).  which: 0 A_query, 1 B_query (G1 half), 2 B_query (G2 half), 3 H_query,
- * 4 L_query, 5 gamma_ABC_g1 (verification key), 6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2, 10 delta_g2, 11 gamma_g2. */
+ * 4 L_query, 5 gamma_ABC_g1 (verification key), 6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2, 10 delta_g2, 11 gamma_g2,
+ * 12 gamma_g1 (extended verification key: the SAVER key generation needs it). */
 size_t vsp_keypair_count(const vsp_keypair *kp, int which);
 int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t *out);
 void vsp_keypair_free(vsp_ctx *ctx, vsp_keypair *kp);
+
+/* ---- SAVER wrapper around the prover: elgamal_verifiable<bls12_381> as the vote phase calls it ----------------
+ *     generate_keypair<elgamal_verifiable>(rnd[3 n + 2], {gg_keypair, n})                common.hpp:921-931      n = msg_size = 25 (:163)
+ *     encrypt<...>(m_field, {d(), pk_eid, gg_keypair, primary_input, auxiliary_input})   common.hpp:1131-1135    <- proves
+ *     rerandomize<...>(rnd[3], ct, {pk_eid, gg_keypair, proof})                          common.hpp:1138-1145
+ * (crypto3-pubkey, absent submodule: the SAVER scheme; member names below are upstream's.)  G_i = gamma_ABC_g1[i], H = G2 generator.
+ *   rnd (3n + 2 scalars)   s_1..s_n | v_1..v_n | t_0..t_n | rho
+ *   public key, flat       delta_g1 (12) | delta_s_g1[i] = s_i delta_g1 (n x 12) | t_g1[i] = t_i G_i (n x 12) | t_g2[j] = t_j H ((n+1) x 24) |
+ *                          delta_sum_s_g1 = (t_0 + sum t_j s_j) delta_g1 (12) | gamma_inverse_sum_s_g1 = -(1 + sum s_j) gamma_g1 (12)
+ *   secret key             rho (4)
+ *   verification key, flat rho_g2 = rho H (24) | rho_sv_g2[i] = s_i v_i H (n x 24) | rho_rhov_g2[i] = rho v_i H (n x 24)
+ *   ciphertext             c_0 = r delta_g1 | c_i = r delta_s_g1[i] + m_i G_i | psi = r delta_sum_s_g1 + sum m_i t_g1[i]     ((n + 2) x 12)
+ * The random values upstream draws from algebraic_random_device (common.hpp:923, 1131, 1139) are explicit inputs here.
+ * gamma_abc_g1 points at the first n + 1 entries of the verification key's accumulation vector (constant term, then the n
+ * message inputs).  Decryption and the two verifications are pairing work on the tally / verifier side, outside this path.
+ * vsp_saver_keygen, vsp_saver_pk_load and vsp_saver_rerandomize are host-only and accept ctx = NULL. */
+typedef struct vsp_saver_pk vsp_saver_pk;
+size_t vsp_saver_pk_words(size_t msg_size);     /* uint64 words of the flat public key */
+size_t vsp_saver_vk_words(size_t msg_size);
+int vsp_saver_keygen(vsp_ctx *ctx, size_t msg_size, const uint64_t delta_g1[12], const uint64_t gamma_g1[12], const uint64_t *gamma_abc_g1,
+                     const uint64_t *rnd, uint64_t *pk_out, uint64_t sk_out[4], uint64_t *vk_out);
+/* public key resident for many votes: validates the G1 elements and builds the fixed-base tables of its msg_size + 3 bases */
+vsp_saver_pk *vsp_saver_pk_load(vsp_ctx *ctx, size_t msg_size, const uint64_t *pk_words, const uint64_t *gamma_abc_g1);
+void vsp_saver_pk_free(vsp_ctx *ctx, vsp_saver_pk *spk);
+size_t vsp_saver_pk_msg_size(const vsp_saver_pk *spk);
+/* encrypt: ciphertext of msg (n x 4, must equal the first n entries of witness = primary || auxiliary) under randomness r_enc, and
+ * the Groth16 proof of the statement with C += r_enc * gamma_inverse_sum_s_g1 (vsp_groth16_prove with explicit r, s).  The
+ * ciphertext is computed on the host while the GPU proves.  ct_out: (n + 2) x 12. */
+int vsp_saver_encrypt(vsp_ctx *ctx, const vsp_saver_pk *spk, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *msg, const uint64_t *witness,
+                      const uint64_t r_enc[4], const uint64_t r[4], const uint64_t s[4],
+                      uint64_t *ct_out, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
+/* rerandomize in place with rnd = (r', z1, z2):  ct_i += r' X_i,  A' = z1 A,  B' = z1^-1 B + z2 delta_g2,
+ * C' = C + (z1 z2) A + r' gamma_inverse_sum_s_g1;  proof_out (may be NULL) receives the 192 compressed bytes of the new proof */
+int vsp_saver_rerandomize(vsp_ctx *ctx, const vsp_saver_pk *spk, const uint64_t delta_g2[24], const uint64_t rnd[12],
+                          uint64_t *ct, uint64_t A[12], uint64_t B[24], uint64_t C[12], uint8_t proof_out[192]);
 
 /* ---- generator-side batch exponentiation (section 8(f).1; also builds synthetic benchmark bases) ---
  * out[i] = scalars[i] * generator, written to DEVICE memory as canonical affine points. */

@@ -211,7 +211,7 @@ class R1CS:
 
 KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "H_query": (3, 12),
              "L_query": (4, 12), "gamma_ABC_g1": (5, 12), "alpha_g1": (6, 12), "beta_g1": (7, 12),
-             "delta_g1": (8, 12), "beta_g2": (9, 24), "delta_g2": (10, 24), "gamma_g2": (11, 24)}
+             "delta_g1": (8, 12), "beta_g2": (9, 24), "delta_g2": (10, 24), "gamma_g2": (11, 24), "gamma_g1": (12, 12)}
 
 
 class Keypair:
@@ -237,3 +237,32 @@ class Keypair:
     def free(self):
         if self.h:
             lib().ref_keypair_free(self.h); self.h = None
+
+
+# ---- SAVER (elgamal_verifiable around the prover): the C restatement; oracle/saver.py is the big-int one with the pairing checks
+def saver_pk_words(n):
+    lib().ref_saver_pk_words.restype = C.c_size_t
+    return lib().ref_saver_pk_words(C.c_size_t(n))
+
+
+def saver_vk_words(n):
+    lib().ref_saver_vk_words.restype = C.c_size_t
+    return lib().ref_saver_vk_words(C.c_size_t(n))
+
+
+def saver_keygen(n, delta_g1, gamma_g1, gamma_abc, rnd):
+    pk = np.zeros(saver_pk_words(n), np.uint64); sk = np.zeros(4, np.uint64); vk = np.zeros(saver_vk_words(n), np.uint64)
+    lib().ref_saver_keygen(C.c_size_t(n), _p(_u64(delta_g1)), _p(_u64(gamma_g1)), _p(_u64(gamma_abc)), _p(_u64(rnd)), _p(pk), _p(sk), _p(vk))
+    return pk, sk, vk
+
+
+def saver_encrypt_ct(n, pk, gamma_abc, msg, r):
+    ct = np.zeros((n + 2, 12), np.uint64)
+    lib().ref_saver_encrypt_ct(C.c_size_t(n), _p(_u64(pk)), _p(_u64(gamma_abc)), _p(_u64(msg)), _p(_u64(r)), _p(ct))
+    return ct
+
+
+def saver_rerandomize(n, pk, delta_g2, rnd3, ct, A, B, Cc):
+    ct, A, B, Cc = (_u64(x).copy() for x in (ct, A, B, Cc))
+    lib().ref_saver_rerandomize(C.c_size_t(n), _p(_u64(pk)), _p(_u64(delta_g2)), _p(_u64(rnd3)), _p(ct), _p(A), _p(B), _p(Cc))
+    return ct.reshape(n + 2, 12), A, B, Cc

@@ -610,7 +610,7 @@ int ref_r1cs_is_satisfied(void *p, const uint64_t *witness) {
 /* ------------------------------------------------------------------ Groth16 keys (a9), generator, prover (a8) */
 typedef struct {
     size_t num_vars, num_inputs, m;
-    g1_aff_t alpha_g1, beta_g1, delta_g1; g2_aff_t beta_g2, delta_g2, gamma_g2;
+    g1_aff_t alpha_g1, beta_g1, delta_g1, gamma_g1; g2_aff_t beta_g2, delta_g2, gamma_g2;
     g1_aff_t *A_query;             /* num_vars+1 */
     g2_aff_t *B_query_g2; g1_aff_t *B_query_g1;   /* num_vars+1 each */
     g1_aff_t *H_query;             /* m-1 */
@@ -666,7 +666,7 @@ void *ref_groth16_generate(void *pcs, const uint64_t *toxic /* 5*4 */) {
     fr_to_canon(c4, &alpha); g1_batch_mul_fixed(&kp->alpha_g1, &G1_GEN, c4, 1);
     fr_to_canon(c4, &beta); g1_batch_mul_fixed(&kp->beta_g1, &G1_GEN, c4, 1); g2_batch_mul_fixed(&kp->beta_g2, &G2_GEN, c4, 1);
     fr_to_canon(c4, &delta); g1_batch_mul_fixed(&kp->delta_g1, &G1_GEN, c4, 1); g2_batch_mul_fixed(&kp->delta_g2, &G2_GEN, c4, 1);
-    fr_to_canon(c4, &gamma); g2_batch_mul_fixed(&kp->gamma_g2, &G2_GEN, c4, 1);
+    fr_to_canon(c4, &gamma); g2_batch_mul_fixed(&kp->gamma_g2, &G2_GEN, c4, 1); g1_batch_mul_fixed(&kp->gamma_g1, &G1_GEN, c4, 1);
     free(u); free(At); free(Bt); free(Ct); free(sc);
     return kp;
 }
@@ -704,7 +704,7 @@ void ref_keypair_free(void *p) { keypair_t *kp = (keypair_t *)p; free(kp->A_quer
 
 /* export a proving-key / verification-key component as canonical limbs.
  * which: 0 A_query(G1), 1 B_query_g1, 2 B_query_g2(G2), 3 H_query, 4 L_query, 5 gamma_ABC_g1,
- *        6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2(G2), 10 delta_g2(G2), 11 gamma_g2(G2) */
+ *        6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2(G2), 10 delta_g2(G2), 11 gamma_g2(G2), 12 gamma_g1 (extended verification key) */
 size_t ref_keypair_count(void *p, int which) {
     keypair_t *kp = (keypair_t *)p;
     switch (which) { case 0: case 1: case 2: return kp->num_vars + 1; case 3: return kp->m - 1; case 4: return kp->num_vars - kp->num_inputs;
@@ -718,6 +718,7 @@ void ref_keypair_export(void *p, int which, uint64_t *out) {
         case 3: g1 = kp->H_query; break; case 4: g1 = kp->L_query; break; case 5: g1 = kp->gamma_ABC_g1; break;
         case 6: g1 = &kp->alpha_g1; break; case 7: g1 = &kp->beta_g1; break; case 8: g1 = &kp->delta_g1; break;
         case 9: g2 = &kp->beta_g2; break; case 10: g2 = &kp->delta_g2; break; case 11: g2 = &kp->gamma_g2; break;
+        case 12: g1 = &kp->gamma_g1; break;
     }
     if (g1) for (size_t i = 0; i < n; i++) g1_aff_store(out + 12 * i, &g1[i]);
     if (g2) for (size_t i = 0; i < n; i++) g2_aff_store(out + 24 * i, &g2[i]);
@@ -764,4 +765,97 @@ void ref_groth16_prove(void *pcs, void *pkp, const uint64_t *witness, const uint
     g2_jac_to_aff(&b, &gB2); g2_aff_store(B_out, &b);
     g1_jac_to_aff(&a, &gC); g1_aff_store(C_out, &a);
     free(z); free(H); free(zc); free(hc);
+}
+
+
+/* ------------------------------------------------------------------ SAVER: elgamal_verifiable around the prover
+ * Restates crypto3-pubkey elgamal_verifiable.hpp (absent submodule, /root/reference/.gitmodules:50) = the SAVER scheme of Lee, Choi,
+ * Kim, Oh ("SAVER: SNARK-friendly, Additively-homomorphic, and Verifiable Encryption and decryption with Rerandomization", fig. 3),
+ * as the reference calls it: generate_keypair(rnd[3n+2], {gg_keypair, msg_size}) (common.hpp:921-931), encrypt(m, {r, pk, gg_keypair,
+ * primary, auxiliary}) (:1131-1135), rerandomize(rnd[3], ct, {pk, gg_keypair, proof}) (:1138-1145).  [UPSTREAM-KNOWLEDGE: member
+ * names and the order in which rnd is consumed follow upstream as remembered; the scheme itself is pinned by the paper and by the
+ * verification equations oracle/saver.py checks with the pairing.]   n = msg_size, G_i = gamma_ABC_g1[i] (i = 1..n: message inputs).
+ *   rnd   : s_1..s_n | v_1..v_n | t_0..t_n | rho
+ *   pk    : delta_g1 | delta_s_g1[i] = s_i delta_g1 | t_g1[i] = t_i G_i | t_g2[j] = t_j H (j = 0..n) |
+ *           delta_sum_s_g1 = (t_0 + sum t_j s_j) delta_g1 | gamma_inverse_sum_s_g1 = -(1 + sum s_j) gamma_g1
+ *   sk    : rho          vk : rho_g2 = rho H | rho_sv_g2[i] = s_i v_i H | rho_rhov_g2[i] = rho v_i H
+ *   ct    : c_0 = r delta_g1 | c_i = r delta_s_g1[i] + m_i G_i | psi = r delta_sum_s_g1 + sum m_i t_g1[i]          (n + 2 points)
+ *   proof : Groth16 proof with C += r gamma_inverse_sum_s_g1 (ref_groth16_prove's P1 / r_enc arguments)
+ * Flat layouts (uint64 canonical limbs): pk = 12 + 12n + 12n + 24(n+1) + 12 + 12 words, vk = 24 + 24n + 24n words. */
+static void g1_mul_canon(g1_jac_t *r, const uint64_t *pt12, const uint64_t k[4]) { g1_aff_t a; g1_jac_t j; g1_aff_load(&a, pt12); g1_jac_from_aff(&j, &a); g1_jac_mul(r, &j, k); }
+static void g1_store_jac(uint64_t *out12, const g1_jac_t *j) { g1_aff_t a; g1_jac_to_aff(&a, j); g1_aff_store(out12, &a); }
+static void g2_store_jac(uint64_t *out24, const g2_jac_t *j) { g2_aff_t a; g2_jac_to_aff(&a, j); g2_aff_store(out24, &a); }
+static void g1_add_canon(g1_jac_t *r, const g1_jac_t *p, const uint64_t *pt12) {       /* r = p + affine point (all-zero = infinity) */
+    g1_aff_t a; g1_aff_load(&a, pt12); g1_jac_t j;
+    if (g1_aff_is_inf(&a)) { *r = *p; return; }
+    g1_jac_from_aff(&j, &a); g1_jac_add(r, p, &j);
+}
+size_t ref_saver_pk_words(size_t n) { return 12 + 12 * n + 12 * n + 24 * (n + 1) + 12 + 12; }
+size_t ref_saver_vk_words(size_t n) { return 24 + 24 * n + 24 * n; }
+
+void ref_saver_keygen(size_t n, const uint64_t *delta_g1, const uint64_t *gamma_g1, const uint64_t *gamma_abc /* (n+1) x 12 */,
+                      const uint64_t *rnd /* (3n+2) x 4 */, uint64_t *pk, uint64_t *sk /* 4 */, uint64_t *vk) {
+    ref_init();
+    const uint64_t *s = rnd, *v = rnd + 4 * n, *t = rnd + 8 * n, *rho = rnd + 4 * (3 * n + 1);
+    uint64_t *p_delta_s = pk + 12, *p_t_g1 = p_delta_s + 12 * n, *p_t_g2 = p_t_g1 + 12 * n, *p_dsum = p_t_g2 + 24 * (n + 1), *p_ginv = p_dsum + 12;
+    memcpy(pk, delta_g1, 96);
+    g1_jac_t j; g2_jac_t j2, h; g2_jac_from_aff(&h, &G2_GEN);
+    fr_t sum_s = FR_R, sum_ts, x, y;                      /* 1 + sum s_j  (FR_R = one) ;  t_0 + sum t_j s_j */
+    fr_from_canon(&sum_ts, t);
+    for (size_t i = 0; i < n; i++) {
+        g1_mul_canon(&j, delta_g1, s + 4 * i); g1_store_jac(p_delta_s + 12 * i, &j);
+        g1_mul_canon(&j, gamma_abc + 12 * (i + 1), t + 4 * (i + 1)); g1_store_jac(p_t_g1 + 12 * i, &j);
+        fr_from_canon(&x, s + 4 * i); fr_add(&sum_s, &sum_s, &x);
+        fr_from_canon(&y, t + 4 * (i + 1)); fr_mul(&y, &y, &x); fr_add(&sum_ts, &sum_ts, &y);
+    }
+    for (size_t jx = 0; jx <= n; jx++) { g2_jac_mul(&j2, &h, t + 4 * jx); g2_store_jac(p_t_g2 + 24 * jx, &j2); }
+    uint64_t c4[4];
+    fr_to_canon(c4, &sum_ts); g1_mul_canon(&j, delta_g1, c4); g1_store_jac(p_dsum, &j);
+    fr_neg(&sum_s, &sum_s); fr_to_canon(c4, &sum_s); g1_mul_canon(&j, gamma_g1, c4); g1_store_jac(p_ginv, &j);
+    memcpy(sk, rho, 32);
+    fr_t r_; fr_from_canon(&r_, rho);
+    g2_jac_mul(&j2, &h, rho); g2_store_jac(vk, &j2);
+    for (size_t i = 0; i < n; i++) {
+        fr_t si, vi; fr_from_canon(&si, s + 4 * i); fr_from_canon(&vi, v + 4 * i);
+        fr_mul(&x, &si, &vi); fr_to_canon(c4, &x); g2_jac_mul(&j2, &h, c4); g2_store_jac(vk + 24 + 24 * i, &j2);
+        fr_mul(&x, &r_, &vi); fr_to_canon(c4, &x); g2_jac_mul(&j2, &h, c4); g2_store_jac(vk + 24 + 24 * n + 24 * i, &j2);
+    }
+}
+
+/* ciphertext part of encrypt (the proof part is ref_groth16_prove with P1 = gamma_inverse_sum_s_g1, r_enc = r) */
+void ref_saver_encrypt_ct(size_t n, const uint64_t *pk, const uint64_t *gamma_abc, const uint64_t *msg /* n x 4 */, const uint64_t *r, uint64_t *ct /* (n+2) x 12 */) {
+    ref_init();
+    const uint64_t *p_delta_s = pk + 12, *p_t_g1 = p_delta_s + 12 * n, *p_dsum = p_t_g1 + 12 * n + 24 * (n + 1);
+    g1_jac_t c, m, psi;
+    g1_mul_canon(&c, pk, r); g1_store_jac(ct, &c);
+    g1_mul_canon(&psi, p_dsum, r);
+    for (size_t i = 0; i < n; i++) {
+        g1_mul_canon(&c, p_delta_s + 12 * i, r);
+        g1_mul_canon(&m, gamma_abc + 12 * (i + 1), msg + 4 * i); g1_jac_add(&c, &c, &m);
+        g1_store_jac(ct + 12 * (i + 1), &c);
+        g1_mul_canon(&m, p_t_g1 + 12 * i, msg + 4 * i); g1_jac_add(&psi, &psi, &m);
+    }
+    g1_store_jac(ct + 12 * (n + 1), &psi);
+}
+
+/* rerandomize: rnd3 = (r', z1, z2);  ct_i += r' X_i, psi += r' delta_sum_s_g1;
+ * A' = z1 A,  B' = z1^-1 B + z2 delta_g2,  C' = C + (z1 z2) A + r' gamma_inverse_sum_s_g1        (all in place) */
+void ref_saver_rerandomize(size_t n, const uint64_t *pk, const uint64_t *delta_g2, const uint64_t *rnd3, uint64_t *ct, uint64_t *A, uint64_t *B, uint64_t *Cc) {
+    ref_init();
+    const uint64_t *rp = rnd3, *z1 = rnd3 + 4, *z2 = rnd3 + 8;
+    const uint64_t *p_delta_s = pk + 12, *p_dsum = p_delta_s + 12 * n + 12 * n + 24 * (n + 1), *p_ginv = p_dsum + 12;
+    g1_jac_t t;
+    for (size_t i = 0; i <= n + 1; i++) {
+        const uint64_t *X = i == 0 ? pk : (i <= n ? p_delta_s + 12 * (i - 1) : p_dsum);
+        g1_mul_canon(&t, X, rp); g1_add_canon(&t, &t, ct + 12 * i); g1_store_jac(ct + 12 * i, &t);
+    }
+    fr_t a, b, zi, zz; fr_from_canon(&a, z1); fr_from_canon(&b, z2); fr_inv(&zi, &a); fr_mul(&zz, &a, &b);
+    uint64_t zi4[4], zz4[4]; fr_to_canon(zi4, &zi); fr_to_canon(zz4, &zz);
+    g1_jac_t nA, nC, u; g2_jac_t nB, w; g2_aff_t b2, d2;
+    g1_mul_canon(&u, A, zz4);                          /* (z1 z2) A, from the ORIGINAL A */
+    g1_mul_canon(&nC, p_ginv, rp); g1_jac_add(&nC, &nC, &u); g1_add_canon(&nC, &nC, Cc);
+    g1_mul_canon(&nA, A, z1);
+    g2_aff_load(&b2, B); g2_jac_from_aff(&nB, &b2); g2_jac_mul(&nB, &nB, zi4);
+    g2_aff_load(&d2, delta_g2); g2_jac_from_aff(&w, &d2); g2_jac_mul(&w, &w, z2); g2_jac_add(&nB, &nB, &w);
+    g1_store_jac(A, &nA); g2_store_jac(B, &nB); g1_store_jac(Cc, &nC);
 }

@@ -72,6 +72,14 @@ PROTOTYPES = {
     "vsp_keypair_count": (_SZ, [_P, _I]),
     "vsp_keypair_export": (_I, [_P, _P, _I, _P]),
     "vsp_keypair_free": (None, [_P, _P]),
+    "vsp_saver_pk_words": (_SZ, [_SZ]),
+    "vsp_saver_vk_words": (_SZ, [_SZ]),
+    "vsp_saver_keygen": (_I, [_P, _SZ, _P, _P, _P, _P, _P, _P, _P]),
+    "vsp_saver_pk_load": (_P, [_P, _SZ, _P, _P]),
+    "vsp_saver_pk_free": (None, [_P, _P]),
+    "vsp_saver_pk_msg_size": (_SZ, [_P]),
+    "vsp_saver_encrypt": (_I, [_P] * 14),
+    "vsp_saver_rerandomize": (_I, [_P] * 9),
     "vsp_fixed_base_mul_g1": (_I, [_P, _P, _SZ, _P]),
     "vsp_fixed_base_mul_g2": (_I, [_P, _P, _SZ, _P]),
     "vsp_selftest_field": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),

@@ -382,7 +382,7 @@ class ProvingKey:
 
 KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "H_query": (3, 12), "L_query": (4, 12),
              "gamma_ABC_g1": (5, 12), "alpha_g1": (6, 12), "beta_g1": (7, 12), "delta_g1": (8, 12), "beta_g2": (9, 24),
-             "delta_g2": (10, 24), "gamma_g2": (11, 24)}
+             "delta_g2": (10, 24), "gamma_g2": (11, 24), "gamma_g1": (12, 12)}
 
 
 class Keypair:
@@ -426,6 +426,61 @@ def groth16_prove(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
     ctx.check(ctx.lib.vsp_groth16_prove(ctx.h, cs.h, pk.h, _ptr(witness), _ptr(_u64(r)), _ptr(_u64(s)), _ptr(p1), _ptr(re),
                                         _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
     return A, B, Cc, proof.tobytes()
+
+
+# ---- SAVER wrapper (f.3): elgamal_verifiable over BLS12-381 around the prover ---------------------------------------------
+def saver_generate_keypair(ctx, rnd, gamma_abc_g1, delta_g1, gamma_g1, msg_size):
+    """generate_keypair<elgamal_verifiable>(rnd, {gg_keypair, msg_size}) (common.hpp:921-931) with the 3 * msg_size + 2 random scalars
+    explicit.  -> (public key words, secret key rho [4], verification key words)"""
+    n = int(msg_size)
+    rnd = _u64(rnd, 4)
+    if rnd.shape[0] != 3 * n + 2:
+        raise ValueError("generate_keypair: 3 * msg_size + 2 random values are needed")
+    gabc = _u64(gamma_abc_g1, 12)
+    if gabc.shape[0] < n + 1:
+        raise ValueError("generate_keypair: the verification key has fewer than msg_size + 1 accumulation elements")
+    pk = np.zeros(ctx.lib.vsp_saver_pk_words(n), np.uint64); sk = np.zeros(4, np.uint64); vk = np.zeros(ctx.lib.vsp_saver_vk_words(n), np.uint64)
+    ctx.check(ctx.lib.vsp_saver_keygen(ctx.h, n, _ptr(_u64(delta_g1)), _ptr(_u64(gamma_g1)), _ptr(gabc), _ptr(rnd), _ptr(pk), _ptr(sk), _ptr(vk)))
+    return pk, sk, vk
+
+
+class SaverPublicKey:
+    """elgamal_verifiable public key resident for many votes (fixed-base tables of its bases)."""
+
+    def __init__(self, ctx, pk_words, gamma_abc_g1, msg_size):
+        self.ctx, self.n = ctx, int(msg_size)
+        self.words = _u64(pk_words)
+        gabc = _u64(gamma_abc_g1, 12)
+        self.h = ctx.lib.vsp_saver_pk_load(ctx.h, self.n, _ptr(self.words), _ptr(gabc))
+        if not self.h:
+            raise VspError("saver_pk_load failed: " + ctx.last_error())
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.vsp_saver_pk_free(self.ctx.h, self.h)
+        self.h = None
+
+
+def saver_encrypt(ctx, spk, cs, pk, msg, witness, r_enc, r, s):
+    """encrypt<elgamal_verifiable, verifiable_encryption>(m, {r_enc, pk_eid, gg_keypair, primary, auxiliary}) (common.hpp:1131-1135):
+    -> (ciphertext [msg_size + 2, 12], (A, B, C), proof bytes)"""
+    witness = _u64(witness, 4); msg = _u64(msg, 4)
+    if witness.shape[0] != cs.num_vars or msg.shape[0] != spk.n:
+        raise ValueError("encrypt: witness must have num_vars entries and the message msg_size blocks")
+    ct = np.zeros((spk.n + 2, 12), np.uint64)
+    A = np.zeros(12, np.uint64); B = np.zeros(24, np.uint64); Cc = np.zeros(12, np.uint64); proof = np.zeros(192, np.uint8)
+    ctx.check(ctx.lib.vsp_saver_encrypt(ctx.h, spk.h, cs.h, pk.h, _ptr(msg), _ptr(witness), _ptr(_u64(r_enc)), _ptr(_u64(r)), _ptr(_u64(s)),
+                                        _ptr(ct), _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
+    return ct, (A, B, Cc), proof.tobytes()
+
+
+def saver_rerandomize(ctx, spk, delta_g2, rnd3, ct, proof_abc):
+    """rerandomize<elgamal_verifiable>(rnd[3], ct, {pk_eid, gg_keypair, proof}) (common.hpp:1138-1145), rnd3 = (r', z1, z2)."""
+    ct = _u64(ct, 12).copy()
+    A, B, Cc = (_u64(x).copy() for x in proof_abc)
+    proof = np.zeros(192, np.uint8)
+    ctx.check(ctx.lib.vsp_saver_rerandomize(ctx.h, spk.h, _ptr(_u64(delta_g2)), _ptr(_u64(rnd3).reshape(12)), _ptr(ct), _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
+    return ct, (A, B, Cc), proof.tobytes()
 
 
 def fixed_base_mul(ctx, d_scalars, n, group=1):

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -128,6 +129,7 @@ struct vsp_keypair {
     vsp_pk *pk = nullptr;
     vsp_bases *q[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // A, B_g1, B_g2, H, L, gamma_ABC_g1
     uint64_t alpha_g1[12], beta_g1[12], delta_g1[12], beta_g2[24], delta_g2[24], gamma_g2[24];
+    uint64_t gamma_g1[12];          // extended verification key (the SAVER key generation needs gamma in G1)
 };
 
 struct vsp_pk {

@@ -143,7 +143,7 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
     auto mul1 = [&](const uint64_t *sc, uint64_t *out) { host_store_g1(out, xyzz_to_affine(xyzz_mul_scalar(xyzz_from_affine(g1), sc, 255))); };
     auto mul2 = [&](const uint64_t *sc, uint64_t *out) { host_store_g2(out, xyzz_to_affine(xyzz_mul_scalar(xyzz_from_affine(g2), sc, 255))); };
     mul1(toxic + 4, kp->alpha_g1); mul1(toxic + 8, kp->beta_g1); mul1(toxic + 16, kp->delta_g1);
-    mul2(toxic + 8, kp->beta_g2); mul2(toxic + 16, kp->delta_g2); mul2(toxic + 12, kp->gamma_g2);
+    mul2(toxic + 8, kp->beta_g2); mul2(toxic + 16, kp->delta_g2); mul2(toxic + 12, kp->gamma_g2); mul1(toxic + 12, kp->gamma_g1);
     kp->pk = vsp_pk_create(ctx, kp->alpha_g1, kp->beta_g1, kp->beta_g2, kp->delta_g1, kp->delta_g2, kp->q[0], kp->q[1], kp->q[2], kp->q[3], kp->q[4]);
     if (!kp->pk || hipStreamSynchronize(st) != hipSuccess) return fail("generate: failed");
     DevBuf *all[] = {&t_lo, &t_hi, &u, &At, &Bt, &Ct, &A_sc, &B_sc, &H_sc, &L_sc, &ABC_sc, &pts, &kbuf};
@@ -154,17 +154,17 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
 const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp) { return kp ? kp->pk : nullptr; }
 
 // which: 0 A_query, 1 B_query_g1, 2 B_query_g2, 3 H_query, 4 L_query, 5 gamma_ABC_g1, 6 alpha_g1, 7 beta_g1, 8 delta_g1,
-//        9 beta_g2, 10 delta_g2, 11 gamma_g2
+//        9 beta_g2, 10 delta_g2, 11 gamma_g2, 12 gamma_g1
 size_t vsp_keypair_count(const vsp_keypair *kp, int which) {
-    if (!kp || which < 0 || which > 11) return 0;
+    if (!kp || which < 0 || which > 12) return 0;
     return which < 6 ? kp->q[which]->n : 1;
 }
 int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t *out) {
     if (!ctx) return VSP_ERR_ARG;
-    if (!kp || !out || which < 0 || which > 11) return set_error(ctx, VSP_ERR_ARG, "keypair_export: bad argument");
+    if (!kp || !out || which < 0 || which > 12) return set_error(ctx, VSP_ERR_ARG, "keypair_export: bad argument");
     if (which >= 6) {
-        const uint64_t *src[] = {kp->alpha_g1, kp->beta_g1, kp->delta_g1, kp->beta_g2, kp->delta_g2, kp->gamma_g2};
-        memcpy(out, src[which - 6], which >= 9 ? 192 : 96);
+        const uint64_t *src[] = {kp->alpha_g1, kp->beta_g1, kp->delta_g1, kp->beta_g2, kp->delta_g2, kp->gamma_g2, kp->gamma_g1};
+        memcpy(out, src[which - 6], (which >= 9 && which <= 11) ? 192 : 96);
         return VSP_OK;
     }
     const vsp_bases *b = kp->q[which];

@@ -122,16 +122,20 @@ void vsp_pk_free(vsp_ctx *, vsp_pk *pk) { delete pk; }
 
 static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
                         const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
-                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
+                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap);
 
-int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
-                      const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
-                      uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
+}  // extern "C"
+namespace vsp {
+// the prover with a hook: `overlap` runs on the host after every kernel is queued and before the first wait -- the window in which
+// the host has nothing to do but wait for the GPU (vsp_saver_encrypt computes its ciphertext there)
+int prove_with_overlap(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4],
+                       const uint64_t *saver_P1, const uint64_t *saver_r_enc, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12],
+                       uint8_t proof_out[192], const std::function<void()> *overlap) {
     if (!ctx) return VSP_ERR_ARG;
     if (!cs || !pk || !witness || !r || !s) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
     if (!fr_canonical(r) || !fr_canonical(s) || (saver_r_enc && !fr_canonical(saver_r_enc)))
         return set_error(ctx, VSP_ERR_ARG, "prove: r, s and r_enc must be canonical (< r)");
-    int rc = prove_queued(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out);
+    int rc = prove_queued(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out, overlap);
     if (rc != VSP_OK) {
         // an early return leaves multi-exponentiations in flight on their own streams, still reading the witness and H vectors:
         // wait for all of them before the caller (or the next call's workspace growth) can touch those buffers
@@ -143,10 +147,18 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
     if (ctx->pr_z.p) hipMemsetAsync(ctx->pr_z.p, 0, ctx->pr_z.cap, ctx->stream);
     return rc;
 }
+}  // namespace vsp
+extern "C" {
+
+int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
+                      const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
+                      uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
+    return prove_with_overlap(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out, nullptr);
+}
 
 static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
                         const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
-                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
+                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap) {
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints;
     const size_t m = cs->dom.m;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
@@ -217,6 +229,7 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     XYZZ<HFp2> s_delta2 = xyzz_mul_scalar(dj2, s, 255);
     XYZZ<HFp> saver = XYZZ<HFp>::inf();
     if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
+    if (overlap && *overlap) (*overlap)();
     lap("prove_host_overlap_ms");
     VSP_TRY(msm_g1_finish(ctx, 1, &eA)); VSP_TRY(msm_g1_finish(ctx, 2, &eB1)); VSP_TRY(msm_g1_finish(ctx, 4, &eL));
     VSP_TRY(msm_g1_finish(ctx, 0, &eH)); VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
