@@ -268,6 +268,38 @@ int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]);
 int vsp_g1_decompress(const uint8_t in[48], int check_subgroup, uint64_t out_affine[12], int *out_is_inf);
 int vsp_g2_decompress(const uint8_t in[96], int check_subgroup, uint64_t out_affine[24], int *out_is_inf);
 
+/* ---- wire formats of the reference's marshaling_policy (common.hpp:168-203 option::big_endian) --------------------
+ * The marshalling sources are absent submodules; csrc/wire.hip lists, field by field, what the reference's own files pin
+ * (proof bytes and the head of the extended verification key: bin/cli/src/data.bin; 8-byte counts and 32-byte scalars:
+ * protocol_exec.ipynb) and what is a stated guess.  All host-only except the proving-key pair.
+ *   scalar vector   8-byte big-endian count | count x 32-byte big-endian Fr          (primary input, eid, sn, rt, voting result)
+ *   G1 vector       8-byte big-endian count | count x 48-byte compressed G1          (the ciphertext)
+ *   proof           A (48) | B (96) | C (48), ZCash compressed                       (data.bin[0:192))
+ *   verification    head (4) | alpha_g1_beta_g2: 12 x 48-byte LITTLE-endian Fp (576, opaque: the pairing lives on the verifier side) |
+ *   key, extended   gamma_g2 (96) | delta_g2 (96) | delta_g1 (48) | count (8) | gamma_ABC_g1 (count x 48) | gamma_g1 (48)
+ *   proving key     alpha_g1 beta_g1 (96 each) beta_g2 (192) delta_g1 (96) delta_g2 (192), ZCash UNCOMPRESSED big-endian, then counted
+ *   ("fast")        vectors A_query (x 96), B_query (x 192 + 96: G2 | G1), H_query (x 96), L_query (x 96)
+ * *_from_blob with a NULL output and a count pointer returns the element count (size query).  VSP_ERR_ARG for malformed input. */
+size_t vsp_fr_vector_blob_size(size_t count);
+int vsp_fr_vector_to_blob(const uint64_t *vals, size_t count, uint8_t *out);
+int vsp_fr_vector_from_blob(const uint8_t *blob, size_t len, uint64_t *vals_out, size_t capacity, size_t *count_out);
+size_t vsp_g1_vector_blob_size(size_t count);
+int vsp_g1_vector_to_blob(const uint64_t *pts, size_t count, uint8_t *out);
+int vsp_g1_vector_from_blob(const uint8_t *blob, size_t len, int check_subgroup, uint64_t *pts_out, size_t capacity, size_t *count_out);
+int vsp_proof_to_blob(const uint64_t A[12], const uint64_t B[24], const uint64_t C[12], uint8_t out[192]);
+int vsp_proof_from_blob(const uint8_t blob[192], int check_subgroup, uint64_t A[12], uint64_t B[24], uint64_t C[12]);
+size_t vsp_vk_blob_size(size_t n_abc);
+int vsp_vk_to_blob(uint32_t head, const uint8_t gt[576], const uint64_t gamma_g2[24], const uint64_t delta_g2[24], const uint64_t delta_g1[12],
+                   const uint64_t *gamma_abc_g1, size_t n_abc, const uint64_t gamma_g1[12], uint8_t *out);
+int vsp_vk_from_blob(const uint8_t *blob, size_t len, int check_subgroup, uint32_t *head, uint8_t gt[576], uint64_t gamma_g2[24], uint64_t delta_g2[24],
+                     uint64_t delta_g1[12], uint64_t *gamma_abc_g1, size_t capacity, size_t *n_abc, uint64_t gamma_g1[12]);
+/* Proving key: the reference deserialises it inside its timed vote phase (common.hpp:1002-1004; main.cpp:446-456).  vsp_pk_from_blob copies
+ * the raw bytes to the GPU once and converts them there (byte order, infinity flags, curve check, Montgomery form, 28-bit-limb table,
+ * optionally the window multiples); the result is a resident key (vsp_keypair_pk) without gamma_ABC_g1. */
+size_t vsp_pk_blob_size(const vsp_keypair *kp);
+int vsp_pk_to_blob(vsp_ctx *ctx, const vsp_keypair *kp, uint8_t *out);
+vsp_keypair *vsp_pk_from_blob(vsp_ctx *ctx, const uint8_t *blob, size_t len, int precompute);
+
 #ifdef __cplusplus
 }
 #endif

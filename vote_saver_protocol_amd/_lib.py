@@ -80,6 +80,20 @@ PROTOTYPES = {
     "vsp_saver_pk_msg_size": (_SZ, [_P]),
     "vsp_saver_encrypt": (_I, [_P] * 14),
     "vsp_saver_rerandomize": (_I, [_P] * 9),
+    "vsp_fr_vector_blob_size": (_SZ, [_SZ]),
+    "vsp_fr_vector_to_blob": (_I, [_P, _SZ, _P]),
+    "vsp_fr_vector_from_blob": (_I, [_P, _SZ, _P, _SZ, _P]),
+    "vsp_g1_vector_blob_size": (_SZ, [_SZ]),
+    "vsp_g1_vector_to_blob": (_I, [_P, _SZ, _P]),
+    "vsp_g1_vector_from_blob": (_I, [_P, _SZ, _I, _P, _SZ, _P]),
+    "vsp_proof_to_blob": (_I, [_P, _P, _P, _P]),
+    "vsp_proof_from_blob": (_I, [_P, _I, _P, _P, _P]),
+    "vsp_vk_blob_size": (_SZ, [_SZ]),
+    "vsp_vk_to_blob": (_I, [C.c_uint32, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "vsp_vk_from_blob": (_I, [_P, _SZ, _I, _P, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "vsp_pk_blob_size": (_SZ, [_P]),
+    "vsp_pk_to_blob": (_I, [_P, _P, _P]),
+    "vsp_pk_from_blob": (_P, [_P, _P, _SZ, _I]),
     "vsp_fixed_base_mul_g1": (_I, [_P, _P, _SZ, _P]),
     "vsp_fixed_base_mul_g2": (_I, [_P, _P, _SZ, _P]),
     "vsp_selftest_field": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),

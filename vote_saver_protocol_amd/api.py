@@ -388,13 +388,29 @@ KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "
 class Keypair:
     """zk::generate<proof_system>(constraint_system) on the GPU with explicit toxic waste [5,4] = (t, alpha, beta, gamma, delta)."""
 
-    def __init__(self, ctx, cs, toxic, precompute=False):
+    def __init__(self, ctx, cs, toxic, precompute=False, _handle=None):
         self.ctx = ctx
-        toxic = _u64(toxic).reshape(20)
-        self.h = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(bool(precompute)))
-        if not self.h:
-            raise VspError("groth16_generate failed: " + ctx.last_error())
+        if _handle is None:
+            toxic = _u64(toxic).reshape(20)
+            _handle = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(bool(precompute)))
+            if not _handle:
+                raise VspError("groth16_generate failed: " + ctx.last_error())
+        self.h = _handle
         self.pk = _BorrowedPk(ctx.lib.vsp_keypair_pk(self.h))
+
+    @classmethod
+    def from_blob(cls, ctx, blob, precompute=False):
+        """deserialize_pk_crs (common.hpp:749-754): the big-endian "fast" proving-key blob -> a resident key, converted on the GPU."""
+        buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+        h = ctx.lib.vsp_pk_from_blob(ctx.h, _ptr(buf), buf.shape[0], int(bool(precompute)))
+        if not h:
+            raise VspError("pk_from_blob failed: " + ctx.last_error())
+        return cls(ctx, None, None, _handle=h)
+
+    def to_blob(self):
+        out = np.zeros(self.ctx.lib.vsp_pk_blob_size(self.h), np.uint8)
+        self.ctx.check(self.ctx.lib.vsp_pk_to_blob(self.ctx.h, self.h, _ptr(out)))
+        return out.tobytes()
 
     def part(self, name):
         which, width = KEY_PARTS[name]
@@ -516,3 +532,80 @@ def g2_decompress(data, check_subgroup=True):
     if _lib.load().vsp_g2_decompress(buf, int(check_subgroup), _ptr(out), C.byref(inf)) != 0:
         raise ValueError("g2_decompress: invalid encoding")
     return out
+
+
+# ---- wire formats (f.2): the big-endian blobs of the reference's marshaling_policy (common.hpp:168-203, 462-485, 749-799) ---------
+def fr_vector_to_blob(vals):
+    """serialize a scalar vector (primary input, eid, sn, rt, voting result): 8-byte count + 32-byte big-endian elements"""
+    vals = _u64(vals, 4)
+    out = np.zeros(_lib.load().vsp_fr_vector_blob_size(vals.shape[0]), np.uint8)
+    if _lib.load().vsp_fr_vector_to_blob(_ptr(vals), vals.shape[0], _ptr(out)) != 0:
+        raise ValueError("fr_vector_to_blob: value not canonical")
+    return out.tobytes()
+
+
+def fr_vector_from_blob(blob):
+    """deserialize_scalar_vector (common.hpp:529-535)"""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8); n = C.c_size_t(0)
+    if _lib.load().vsp_fr_vector_from_blob(_ptr(buf), buf.shape[0], None, 0, C.byref(n)) != 0:
+        raise ValueError("fr_vector_from_blob: malformed blob")
+    out = np.zeros((n.value, 4), np.uint64)
+    if _lib.load().vsp_fr_vector_from_blob(_ptr(buf), buf.shape[0], _ptr(out), n.value, C.byref(n)) != 0:
+        raise ValueError("fr_vector_from_blob: element not canonical")
+    return out
+
+
+def g1_vector_to_blob(pts):
+    """serialize the ciphertext (common.hpp:471-474): 8-byte count + compressed G1 points"""
+    pts = _u64(pts, 12)
+    out = np.zeros(_lib.load().vsp_g1_vector_blob_size(pts.shape[0]), np.uint8)
+    if _lib.load().vsp_g1_vector_to_blob(_ptr(pts), pts.shape[0], _ptr(out)) != 0:
+        raise ValueError("g1_vector_to_blob failed")
+    return out.tobytes()
+
+
+def g1_vector_from_blob(blob, check_subgroup=True):
+    """deserialize_ct (common.hpp:773-781)"""
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8); n = C.c_size_t(0)
+    if _lib.load().vsp_g1_vector_from_blob(_ptr(buf), buf.shape[0], int(check_subgroup), None, 0, C.byref(n)) != 0:
+        raise ValueError("g1_vector_from_blob: malformed blob")
+    out = np.zeros((n.value, 12), np.uint64)
+    if _lib.load().vsp_g1_vector_from_blob(_ptr(buf), buf.shape[0], int(check_subgroup), _ptr(out), n.value, C.byref(n)) != 0:
+        raise ValueError("g1_vector_from_blob: invalid point")
+    return out
+
+
+def proof_from_blob(blob, check_subgroup=True):
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8)
+    if buf.shape[0] != 192:
+        raise ValueError("proof_from_blob: a proof is 192 bytes")
+    A = np.zeros(12, np.uint64); B = np.zeros(24, np.uint64); Cc = np.zeros(12, np.uint64)
+    if _lib.load().vsp_proof_from_blob(_ptr(buf), int(check_subgroup), _ptr(A), _ptr(B), _ptr(Cc)) != 0:
+        raise ValueError("proof_from_blob: invalid encoding")
+    return A, B, Cc
+
+
+def vk_to_blob(gt_bytes, gamma_g2, delta_g2, delta_g1, gamma_abc_g1, gamma_g1, head=0):
+    """extended verification key; gt_bytes = alpha_g1_beta_g2 as 576 opaque bytes (12 little-endian Fp, computed by whoever has the pairing)"""
+    gabc = _u64(gamma_abc_g1, 12); gt = np.frombuffer(bytes(gt_bytes), dtype=np.uint8)
+    if gt.shape[0] != 576:
+        raise ValueError("vk_to_blob: alpha_g1_beta_g2 is 576 bytes")
+    out = np.zeros(_lib.load().vsp_vk_blob_size(gabc.shape[0]), np.uint8)
+    if _lib.load().vsp_vk_to_blob(int(head), _ptr(gt), _ptr(_u64(gamma_g2)), _ptr(_u64(delta_g2)), _ptr(_u64(delta_g1)), _ptr(gabc), gabc.shape[0],
+                                  _ptr(_u64(gamma_g1)), _ptr(out)) != 0:
+        raise ValueError("vk_to_blob failed")
+    return out.tobytes()
+
+
+def vk_from_blob(blob, check_subgroup=True):
+    buf = np.frombuffer(bytes(blob), dtype=np.uint8); n = C.c_size_t(0)
+    lib = _lib.load()
+    if lib.vsp_vk_from_blob(_ptr(buf), buf.shape[0], 0, None, None, None, None, None, None, 0, C.byref(n), None) != 0:
+        raise ValueError("vk_from_blob: malformed blob")
+    head = C.c_uint32(0); gt = np.zeros(576, np.uint8)
+    g2 = np.zeros(24, np.uint64); d2 = np.zeros(24, np.uint64); d1 = np.zeros(12, np.uint64); g1 = np.zeros(12, np.uint64)
+    gabc = np.zeros((n.value, 12), np.uint64)
+    if lib.vsp_vk_from_blob(_ptr(buf), buf.shape[0], int(check_subgroup), C.byref(head), _ptr(gt), _ptr(g2), _ptr(d2), _ptr(d1), _ptr(gabc), n.value,
+                            C.byref(n), _ptr(g1)) != 0:
+        raise ValueError("vk_from_blob: invalid point")
+    return dict(head=head.value, alpha_g1_beta_g2=gt.tobytes(), gamma_g2=g2, delta_g2=d2, delta_g1=d1, gamma_ABC_g1=gabc, gamma_g1=g1)

@@ -157,7 +157,7 @@ const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp) { return kp ? kp->pk : nullp
 //        9 beta_g2, 10 delta_g2, 11 gamma_g2, 12 gamma_g1
 size_t vsp_keypair_count(const vsp_keypair *kp, int which) {
     if (!kp || which < 0 || which > 12) return 0;
-    return which < 6 ? kp->q[which]->n : 1;
+    return which < 6 ? (kp->q[which] ? kp->q[which]->n : 0) : 1;       // a key loaded from a proving-key blob has no gamma_ABC_g1
 }
 int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t *out) {
     if (!ctx) return VSP_ERR_ARG;
@@ -168,7 +168,7 @@ int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t 
         return VSP_OK;
     }
     const vsp_bases *b = kp->q[which];
-    if (!b->n) return VSP_OK;
+    if (!b || !b->n) return VSP_OK;
     VSP_HIP(hipSetDevice(ctx->device));
     size_t esz = b->group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
     DevBuf tmp;
