@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_PAIR = {1: 128, 2: 224}   # affine base (96 / 192 B) + 32 B scalar
-MADS_PER_ADD = {1: 8 * 392 + 588, 2: 2 * (8 * 588 + 2 * 392)}   # v_mad_u64_u32 per mixed addition (G2: two lanes per point)
+MADS_PER_ADD = {1: 6 * 392 + 2 * 301 + 588, 2: 2 * (8 * 588 + 2 * 392)}   # v_mad_u64_u32 per mixed addition: 6 products, 2 squares, 1 dual product (G2: two lanes per point)
 VALU_PEAK_MADS = 1.46e9 * 64 * 256  # measured v_mad_u64_u32 issue peak (profiles/r1_ubench_valu.txt): wave-instr/s/CU x lanes x CUs
 PMC_FILES = ("r2_pmc_hbm_traffic.json", "r1_h_pmc_hbm_traffic.json")   # newest first; see profiles/README.md
 
@@ -99,7 +99,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     ni = 30
     nc = (1 << log_m) - ni - 2
     gen = o.splitmix64(5)
-    cs, wit = cref.R1CS.synth(nc, ni, 4)
+    cs, wit = cref.R1CS.synth(nc, ni, 4, ballot=(25, 7))      # the first 25 public inputs are a one-hot ballot (msg_size = 25, common.hpp:163, 1029-1040)
     tox_i = [o.rand_fr(gen) for _ in range(5)]
     tox = np.array([o.int_to_limbs(x, 4) for x in tox_i], dtype=np.uint64)
     A, B, Cm = cs.export()

@@ -163,10 +163,13 @@ class R1CS:
         self.is_step = bool(lib().ref_r1cs_domain_is_step(self.h))
 
     @classmethod
-    def synth(cls, num_constraints, num_inputs, seed):
+    def synth(cls, num_constraints, num_inputs, seed, ballot=None):
+        """ballot = (msg_size, vote): the first msg_size public inputs are the one-hot ballot m[vote] = 1 (common.hpp:1029-1040)"""
         nv = num_constraints + num_inputs
         wit = np.zeros((nv, 4), np.uint64)
-        h = lib().ref_r1cs_synth(C.c_size_t(num_constraints), C.c_size_t(num_inputs), C.c_uint64(seed), _p(wit))
+        lib().ref_r1cs_synth_ballot.restype = C.c_void_p
+        msg_size, vote = ballot if ballot else (0, 0)
+        h = lib().ref_r1cs_synth_ballot(C.c_size_t(num_constraints), C.c_size_t(num_inputs), C.c_uint64(seed), C.c_size_t(msg_size), C.c_size_t(vote), _p(wit))
         cs = cls(h, num_constraints, num_inputs)
         return cs, wit
 

@@ -481,7 +481,13 @@ static void rand_fr_canon(uint64_t *s, uint64_t out[4]) {
  *   boolean wire (90%):  z_k * z_k = z_k,  z_k in {0,1}
  *   product wire (10%):  z_a * z_b = z_k,  a,b < k
  * 3 sparse terms per row.  Fills the canonical witness z[1..num_vars] (4 limbs each). */
+void *ref_r1cs_synth_ballot(size_t num_constraints, size_t num_inputs, uint64_t seed, size_t msg_size, size_t vote, uint64_t *witness_out);
 void *ref_r1cs_synth(size_t num_constraints, size_t num_inputs, uint64_t seed, uint64_t *witness_out /* num_vars*4 */) {
+    return ref_r1cs_synth_ballot(num_constraints, num_inputs, seed, 0, 0, witness_out);
+}
+/* the same instance with a BALLOT in the first msg_size public inputs: one-hot at `vote` (the reference's m_field, common.hpp:1029-1040:
+ * m[vote] = true); the remaining inputs stay random field elements (eid / sn / rt are packed field elements there too) */
+void *ref_r1cs_synth_ballot(size_t num_constraints, size_t num_inputs, uint64_t seed, size_t msg_size, size_t vote, uint64_t *witness_out /* num_vars*4 */) {
     ref_init();
     r1cs_t *cs = (r1cs_t *)calloc(1, sizeof *cs);
     cs->num_constraints = num_constraints; cs->num_inputs = num_inputs; cs->num_vars = num_inputs + num_constraints;
@@ -492,6 +498,7 @@ void *ref_r1cs_synth(size_t num_constraints, size_t num_inputs, uint64_t seed, u
     }
     uint64_t s = seed;
     for (size_t k = 1; k <= num_inputs; k++) rand_fr_canon(&s, witness_out + 4 * (k - 1));
+    for (size_t k = 1; k <= msg_size && k <= num_inputs; k++) { memset(witness_out + 4 * (k - 1), 0, 32); witness_out[4 * (k - 1)] = (k - 1 == vote) ? 1 : 0; }
     fr_t *z = (fr_t *)malloc((cs->num_vars + 1) * sizeof *z);
     z[0] = FR_R;
     for (size_t k = 1; k <= num_inputs; k++) fr_from_canon(&z[k], witness_out + 4 * (k - 1));

@@ -105,6 +105,36 @@ def mm28(a, b, c=None, d=None):
     return r
 
 
+def sq28(a):
+    """vsp_sq28 (tools/gen_mont_asm.py body28(sqr=True)): off-diagonal products once against 2a, diagonal ones a_i * a_i.  Column by
+    column the totals equal those of mm28(a, a), so the same m_k and the same output -- asserted here, with the tight-operand
+    precondition the kernel relies on."""
+    need(all(0 <= t <= MASK for t in a[:-1]) and a[-1] < 1 << 28, "squaring operand not tight")
+    a2 = [2 * t for t in a]
+    m = [0] * N
+    r = [0] * N
+    acc = 0
+    for k in range(2 * N - 1):
+        for i in range(max(0, k - N + 1), min(k, N - 1) + 1):
+            if i < k - i:
+                acc += a[i] * a2[k - i]
+            elif i == k - i:
+                acc += a[i] * a[i]
+        for i in (range(0, k) if k < N else range(k - N + 1, N)):
+            acc += m[i] * PL[k - i]
+        if k < N:
+            m[k] = (((acc & 0xFFFFFFFF) * INV28) & 0xFFFFFFFF) & MASK
+            acc += m[k] * PL[0]
+        else:
+            r[k - N] = acc & MASK
+        need(acc < 1 << 64, "column %d of the square overflows" % k)
+        acc >>= W
+    need(acc < 1 << 32, "top limb of the square overflows")
+    r[N - 1] = acc
+    need(r == mm28(a, a), "dedicated square differs from the product a * a")
+    return r
+
+
 def sub28(a, k, b):
     r = []
     for i in range(N):
@@ -156,14 +186,14 @@ def madd28(acc, q, negate):
     U2 = mm28(qx, ZZ)
     S2 = mm28(qyn, ZZZ)
     Pd = norm28(sub28(U2, K["FP28_K32_L1"], X))
-    PP = mm28(Pd, Pd)
+    PP = sq28(Pd)
     if is_zero_product(PP, 2):
         return acc, False
     R = norm28(sub28(S2, K["FP28_K32_L1"], Y))
     PPP = mm28(Pd, PP)
     Q = mm28(X, PP)
     s = lin(PPP, 1, Q, 2)
-    X3 = norm28(sub28(mm28(R, R), K["FP28_K8_L4"], s))
+    X3 = norm28(sub28(sq28(R), K["FP28_K8_L4"], s))
     Y3 = mm28(R, sub28(Q, K["FP28_K32_L1"], X3), neg28(K["FP28_K32_L1"], Y), PPP)
     return (X3, Y3, mm28(ZZ, PP), mm28(ZZZ, PPP)), True
 

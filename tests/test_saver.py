@@ -19,9 +19,9 @@ from conftest import I, L, fr_array
 import vote_saver_protocol_amd as v
 
 
-def _setup(cref, n, nc, ni, seed):
+def _setup(cref, n, nc, ni, seed, ballot=None):
     gen = o.splitmix64(seed)
-    cs, wit = cref.R1CS.synth(nc, ni, seed)
+    cs, wit = cref.R1CS.synth(nc, ni, seed, ballot=ballot)
     tox = fr_array([o.rand_fr(gen) for _ in range(5)])
     kp = cref.Keypair(cs, tox)
     rnd = fr_array([o.rand_fr(gen) for _ in range(3 * n + 2)])
@@ -180,3 +180,52 @@ def test_gpu_encrypt_and_rerandomize_msg_size_25(ctx, cref):
     ea, eb, ec = kp.prove(wit, r, s)
     assert np.array_equal(pa, ea) and np.array_equal(pb, eb) and np.array_equal(pc, ec)
     spk.free(); pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+@pytest.mark.gpu
+def test_gpu_one_hot_ballot_tally_of_three_voters(ctx, cref):
+    """the protocol end to end at msg_size = 25 with real ballots: three voters vote (one-hot messages in the first 25 public inputs,
+    common.hpp:1029-1040), each ballot = vsp_saver_encrypt + vsp_saver_rerandomize and verifies; the tally of the three ciphertexts
+    (common.hpp:1208-1216) decrypts to the vote counts and the decryption proof verifies."""
+    n, ni, nc = 25, 30, 600
+    votes = (7, 3, 7)
+    gen = o.splitmix64(99)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    rnd = fr_array([o.rand_fr(gen) for _ in range(3 * n + 2)])
+    cts = []
+    spk = pkd = vkd = rho = gabc = None
+    for voter, vote in enumerate(votes):
+        cs, wit = cref.R1CS.synth(nc, ni, 5, ballot=(n, vote))                 # the same circuit, another ballot
+        assert [I(x) for x in wit[:n]] == [1 if i == vote else 0 for i in range(n)]
+        kp = cref.Keypair(cs, tox)
+        parts = {k: kp.part(k) for k in ("gamma_ABC_g1", "delta_g1", "gamma_g1", "alpha_g1", "beta_g2", "gamma_g2", "delta_g2")}
+        gabc_l = np.ascontiguousarray(parts["gamma_ABC_g1"])
+        if spk is None:
+            pk_w, sk, vk_w = v.saver_generate_keypair(ctx, rnd, gabc_l, parts["delta_g1"][0], parts["gamma_g1"][0], n)
+            spk = v.SaverPublicKey(ctx, pk_w, gabc_l[:n + 1], n)
+            pkd, vkd, rho = sv.pk_from_words(pk_w, n), sv.vk_from_words(vk_w, n), I(sk)
+            gabc = [o.g1_from_limbs(x) for x in gabc_l]
+        dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
+        q = [ctx.upload_bases(kp.part(nm), g) for nm, g in (("A_query", 1), ("B_query_g1", 1), ("B_query_g2", 2), ("H_query", 1), ("L_query", 1))]
+        pk = v.ProvingKey(ctx, kp.part("alpha_g1")[0], kp.part("beta_g1")[0], kp.part("beta_g2")[0], kp.part("delta_g1")[0], kp.part("delta_g2")[0], *q)
+        r_enc, r, s = (L(o.rand_fr(gen), 4) for _ in range(3))
+        ct, abc, _ = v.saver_encrypt(ctx, spk, dcs, pk, wit[:n], wit, r_enc, r, s)
+        ct, abc, _ = v.saver_rerandomize(ctx, spk, parts["delta_g2"][0], fr_array([o.rand_fr(gen) for _ in range(3)]), ct, abc)
+        if voter == 0:                                                          # the pairing check is slow in pure Python: one ballot
+            assert sv.verify_encryption(pkd, _gg_vk(parts), _ct_points(ct), (o.g1_from_limbs(abc[0]), o.g2_from_limbs(abc[1]), o.g1_from_limbs(abc[2])),
+                                        [I(wit[i]) for i in range(n, ni)])
+        # the ciphertext travels as a blob (common.hpp:471-474) and comes back intact
+        assert np.array_equal(v.g1_vector_from_blob(v.g1_vector_to_blob(ct)), ct)
+        cts.append(_ct_points(ct))
+        pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+    agg = sv.add_ciphertexts(cts)
+    # decrypt three positions (each costs pairings in pure Python): the two that received votes and an empty one
+    sub = [0, 3, 7]
+    pick = lambda lst: [lst[i] for i in sub]
+    vk3 = dict(rho_g2=vkd["rho_g2"], rho_sv_g2=pick(vkd["rho_sv_g2"]), rho_rhov_g2=pick(vkd["rho_rhov_g2"]))
+    agg3 = [agg[0]] + [agg[i + 1] for i in sub] + [agg[n + 1]]
+    gabc3 = [gabc[0]] + [gabc[i + 1] for i in sub]
+    got, nu = sv.decrypt(rho, vk3, gabc3, agg3, max_value=8)
+    assert got == [0, 1, 2]
+    assert sv.verify_decryption(vk3, gabc3, agg3, got, nu) and not sv.verify_decryption(vk3, gabc3, agg3, [0, 2, 1], nu)
+    spk.free()

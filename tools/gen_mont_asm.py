@@ -125,12 +125,15 @@ N28, W28 = 14, 28
 MASK28 = (1 << W28) - 1
 
 
-def body28(dual=False):
+def body28(dual=False, sqr=False):
     """Column sums of 28 products below 2^58 fit a 64-bit accumulator, so no v_addc follows the mads; per column one 64-bit shift
     and one mask.  Operand limbs may be loose: limb bounds 2^Ea, 2^Eb with Ea + Eb <= 59.  Output: limbs below 2^28 (the top limb
     holds the rest), value below a*b / 2^392 + p -- no final subtraction.  a, b are preserved.
     dual: a*b + c*d into the same column accumulators, one reduction (the sum of the two groups of 14 products must stay
-    below 2^64 - 2^60: e.g. limb bounds 28+30 and 31+28)."""
+    below 2^64 - 2^60: e.g. limb bounds 28+30 and 31+28).
+    sqr: a*a with the caller passing b = 2a limb by limb: the off-diagonal products a_i a_j, i < j, are taken once against the doubled
+    operand (a_i * 2a_j), the diagonal ones as a_i * a_i -- 105 limb products for the square instead of 196, the same column totals,
+    hence the same m_k and bit-identical output.  Limb bound of a: 2^28 (then 2a < 2^29 and a column stays below 2^61)."""
     nin = 4 if dual else 2
     A = lambda i: f"v{i}"
     B = lambda i: f"v{N28 + i}"
@@ -144,6 +147,12 @@ def body28(dual=False):
     ins = [f"v_mov_b32 {lo}, 0", f"v_mov_b32 {hi}, 0"]
     for k in range(2 * N28 - 1):
         for i in range(max(0, k - N28 + 1), min(k, N28 - 1) + 1):
+            if sqr:
+                if i < k - i:
+                    ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {B(k - i)}, {pr}")       # a_i * (2 a_j)
+                elif i == k - i:
+                    ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {A(i)}, {pr}")
+                continue
             ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {B(k - i)}, {pr}")
             if dual:
                 ins.append(f"v_mad_u64_u32 {pr}, vcc, {C(i)}, {D(k - i)}, {pr}")
@@ -204,6 +213,13 @@ def gen28():
     inps2 = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N28)] + [f'"{{v{N28 + i}}}"(b[{i}])' for i in range(N28)] +
                       [f'"{{v{2 * N28 + i}}}"(c[{i}])' for i in range(N28)] + [f'"{{v{3 * N28 + i}}}"(d[{i}])' for i in range(N28)])
     n_mad2 = sum(1 for x in ins2 if x.startswith("v_mad"))
+    # squaring variant: same register map as the single product (a in v0..13, 2a in v14..27, result v28..41)
+    ins3 = body28(sqr=True)
+    lines3 = ['s_branch .Lvsp_sq28_end', '.p2align 8', 'vsp_sq28:']
+    lines3 += [f's_mov_b32 s{i}, 0x{p28[i]:x}' for i in range(N28)] + [f's_mov_b32 s14, 0x{inv28:x}', f's_mov_b32 s15, 0x{MASK28:x}']
+    lines3 += ins3 + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_sq28_end:']
+    body3_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines3)
+    n_mad3 = sum(1 for x in ins3 if x.startswith("v_mad"))
     return f"""// ---- Fp on 14 x 28-bit limbs, R' = 2^392: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v44 ----
 // constants: p; R' mod p (the Montgomery one); R'^2 mod p; and multiples of p in the redundant form used by the lazy subtractions
 // (FP28_Kc_Ll = c*p with every limb but the top raised by l * 2^28)
@@ -223,6 +239,23 @@ __device__ __forceinline__ void mont_mul28_asm(uint32_t *r, const uint32_t *a, c
         "s_swappc_b64 s[30:31], s[30:31]"
         : {outs}
         : {inps}
+        : "vcc", "scc", "s30", "s31", {sclob}, "v42", "v43", "v44");
+}}
+// ---- the square: r = a*a*2^(-392) with a2 = 2a passed by the caller; {n_mad3} v_mad_u64_u32, {len(ins3)} instructions; bit-identical to mont_mul28_asm(r, a, a)
+template <int Instance> __device__ __attribute__((noinline, used)) void mont_sqr28_holder() {{
+    asm volatile(
+{body3_txt}
+        :
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclob});
+}}
+__device__ __forceinline__ void mont_sqr28_asm(uint32_t *r, const uint32_t *a, const uint32_t *a2) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, vsp_sq28@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, vsp_sq28@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outs}
+        : {inps.replace("(b[", "(a2[")}
         : "vcc", "scc", "s30", "s31", {sclob}, "v42", "v43", "v44");
 }}
 // ---- the same for a*b + c*d with one reduction: {n_mad2} v_mad_u64_u32, {len(ins2)} instructions; operands v0..v55 (preserved), result v56..v69 ----

@@ -83,6 +83,7 @@ struct vsp_ctx {
     vsp::MsmWork msm_work[vsp::VSP_MSM_SLOTS];
     int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
     bool lds_attr_set[2] = {false, false};
+    bool ntt_attr_set = false;
     vsp::DevBuf msm_scalars;
     vsp::DevBuf val_flag;               // one word: validation result of the last bases upload
     int fp28_checked[2] = {0, 0};       // known-answer check of the 28-bit-limb accumulation kernels, per group: 0 not yet, 1 passed, -1 failed (kernel disabled)

@@ -28,9 +28,14 @@
 
 namespace vsp {
 
-static constexpr unsigned NTT_TILE_LOG = 11;      // 2048 elements per workgroup
-static constexpr unsigned NTT_THREADS = 512;     // 2 workgroups per CU (64 KiB tiles) -> 4 waves per SIMD (256: 0.81 ms, 512: 0.74 ms, 1024: 0.84 ms at 2^22)
-static constexpr unsigned NTT_MAX_STAGES = 8;     // per pass (keeps C >= 8 columns = 256 B runs)
+#ifndef VSP_NTT_TILE_LOG
+#define VSP_NTT_TILE_LOG 11
+#define VSP_NTT_THREADS 512
+#define VSP_NTT_MAX_STAGES 8
+#endif
+static constexpr unsigned NTT_TILE_LOG = VSP_NTT_TILE_LOG;      // 2048 elements per workgroup
+static constexpr unsigned NTT_THREADS = VSP_NTT_THREADS;     // 2 workgroups per CU (64 KiB tiles) -> 4 waves per SIMD (256: 0.81 ms, 512: 0.74 ms, 1024: 0.84 ms at 2^22)
+static constexpr unsigned NTT_MAX_STAGES = VSP_NTT_MAX_STAGES;     // per pass (keeps C >= 8 columns = 256 B runs)
 static constexpr unsigned PW_LOG = 11;            // two-level power tables: g^i = lo[i & 2047] * hi[i >> 11]
 
 struct NttPassArgs {
