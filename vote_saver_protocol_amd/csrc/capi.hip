@@ -214,7 +214,7 @@ int vsp_host_unregister(vsp_ctx *ctx, void *ptr) {
 // multi-exponentiation over the first points of the new bases runs through k_accum28 and through the generic 12 x 32-bit k_accum;
 // the two affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0):
 // every later multi-exponentiation takes the generic kernel.  Returns true when the table may be used.
-static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void *t28, size_t count) {
+static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void *t28, size_t count, bool glv) {
     const int gi = b->group - 1;
     if (ctx->fp28_checked[gi] != 0) return ctx->fp28_checked[gi] > 0;
     if (ctx->msm_work[0].active) return true;                 // slot 0 busy (unusual): check at the next table instead
@@ -233,14 +233,14 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void
         const Fr *ds = (const Fr *)ctx->msm_scalars.p;
         if (b->group == 1) {
             XYZZ<HFp> r28, rgen;
-            if (msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28) == VSP_OK && msm_g1_finish(ctx, 0, &r28) == VSP_OK &&
+            if (msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28, glv) == VSP_OK && msm_g1_finish(ctx, 0, &r28) == VSP_OK &&
                 msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g1_finish(ctx, 0, &rgen) == VSP_OK) {
                 Affine<HFp> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
                 same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
             }
         } else {
             XYZZ<HFp2> r28, rgen;
-            if (msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28) == VSP_OK && msm_g2_finish(ctx, 0, &r28) == VSP_OK &&
+            if (msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28, glv) == VSP_OK && msm_g2_finish(ctx, 0, &r28) == VSP_OK &&
                 msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g2_finish(ctx, 0, &rgen) == VSP_OK) {
                 Affine<HFp2> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
                 same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
@@ -253,15 +253,25 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void
     if (!same) { ctx->opts["msm_fp28"] = 0; ctx->err = "msm: the 28-bit-limb accumulation kernel failed its known-answer check; generic kernel in use"; }
     return same;
 }
-// the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off
+// the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off.
+// Plain bases (no window multiples) get the endomorphism layout: 2 count rows, (P_i, phi(P_i)) interleaved (option "msm_glv" = 0: off)
 static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     if (b->d28) { hipFree(b->d28); b->d28 = nullptr; }
+    b->glv = false;
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
-    void *t28 = nullptr;
+    long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
     const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
-    if (!want || hipMalloc(&t28, count * row) != hipSuccess) { hipGetLastError(); return; }
-    int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28);
-    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess && fp28_known_answer_check(ctx, b, t28, b->n < count ? b->n : count)) b->d28 = t28;
+    // The split halves the bucket sets but doubles the table.  Measured (tools/msm_sizes.py, blocking / three in flight, ms): G1 2^16
+    // 1.48 / 1.37 -> 1.26 / 0.77, G1 2^18 2.30 / 1.29 -> 2.05 / 1.23, G2 2^16 2.99 / 1.48 -> 2.55 / 1.36 -- but G1 2^19 2.82 -> 3.09 and
+    // G1 2^20: the 256 MB interleaved table no longer sits in the Infinity Cache beside the sort's arrays and one accumulation goes
+    // from 2.62 to 3.22 ms, more than the bucket reduction gives back.  So: on while the doubled table is at most 64 MB (2^18 G1 /
+    // 2^17 G2 points -- the size class of the reference's real circuit); "msm_glv" = 2 forces it on.
+    const bool glv = want_glv && b->pre_c == 0 && count < ((size_t)1 << 30) && (want_glv >= 2 || 2 * count * row <= ((size_t)64 << 20));
+    void *t28 = nullptr;
+    if (!want || hipMalloc(&t28, count * row * (glv ? 2 : 1)) != hipSuccess) { hipGetLastError(); return; }
+    int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28, glv) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28, glv);
+    // the known-answer check runs over plain points: a table of window multiples is checked through its first slice, read as plain bases
+    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess && fp28_known_answer_check(ctx, b, t28, b->n < count ? b->n : count, glv)) { b->d28 = t28; b->glv = glv; }
     else { hipFree(t28); hipGetLastError(); }
 }
 extern "C" {
@@ -322,9 +332,9 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
     }
     if (bases->group == 1)
         return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
-                             bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28) : nullptr);
+                             bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28) * (bases->glv ? 2 : 1) : nullptr, bases->glv);
     return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
-                         bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28x2) : nullptr);
+                         bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28x2) * (bases->glv ? 2 : 1) : nullptr, bases->glv);
 }
 }  // namespace vsp
 extern "C" {

@@ -42,6 +42,7 @@ struct MsmGeom {
     unsigned Wr;        // bucket sets: W (one per window) or 1 (precomputed window multiples, all windows share one set)
     unsigned single;    // 1 in the shared-set mode
     uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
+    unsigned sbits;     // bits of a scalar the windows must cover: 255, or 128 for the two halves of an endomorphism-split scalar
 };
 // reference to the precomputed window multiples of resident bases
 struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null
@@ -54,6 +55,8 @@ struct MsmWork {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres, medium, redo;
+    DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
+    bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
     void *h_pinned = nullptr;
     void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
     hipEvent_t census_done = nullptr;
@@ -99,6 +102,8 @@ struct vsp_bases {
     void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
                             // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
     unsigned pre_c = 0;
+    bool glv = false;       // plain bases only: d28 holds 2n rows, (P_i, phi(P_i)) interleaved, phi(x, y) = (beta x, y) = lambda * P (the curve's
+                            // endomorphism): a scalar k = k1 + k2 lambda then needs windows over 128 bits only -- half the bucket sets to reduce
     void *d28 = nullptr;    // the same array (or table) once more on 14 x 28-bit limbs (fp28.h: 112-byte rows G1, 224-byte rows G2) for the accumulation kernel
 };
 
@@ -177,14 +182,14 @@ int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, const vsp_domain *d
 int msm_g1_device(vsp_ctx *ctx, const G1Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp> *out);
 int msm_g2_device(vsp_ctx *ctx, const G2Affine *d_bases, const Fr *d_scalars, size_t n, XYZZ<HFp2> *out);
 int msm_g1_launch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre,
-                  const void *plain_table28 = nullptr);   // plain bases (pre == null): the same points as Affine28, or null
+                  const void *plain_table28 = nullptr, bool glv = false);   // plain bases (pre == null): the same points as Affine28 (glv: 2n rows, P and phi(P) interleaved), or null
 int msm_g1_precompute(vsp_ctx *ctx, G1Affine *table, size_t n, unsigned c);
 int msm_g2_precompute(vsp_ctx *ctx, G2Affine *table, size_t n, unsigned c);
-int msm_g1_table28(vsp_ctx *ctx, const G1Affine *table, size_t count, void *d_out /* count x 112 bytes */);
-int msm_g2_table28(vsp_ctx *ctx, const G2Affine *table, size_t count, void *d_out /* count x 224 bytes */);
+int msm_g1_table28(vsp_ctx *ctx, const G1Affine *table, size_t count, void *d_out /* count (glv: 2 count) rows of 128 bytes */, bool glv);
+int msm_g2_table28(vsp_ctx *ctx, const G2Affine *table, size_t count, void *d_out /* count (glv: 2 count) rows of 256 bytes */, bool glv);
 int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
 int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre,
-                  const void *plain_table28 = nullptr);
+                  const void *plain_table28 = nullptr, bool glv = false);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
