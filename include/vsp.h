@@ -204,8 +204,9 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
 /* ---- Groth16 generator: zk::generate<proof_system>(constraint_system), bin/cli/.../common.hpp:916-917 ----
  * r1cs_gg_ppzksnark_generator with explicit toxic waste toxic[20] = (t, alpha, beta, gamma, delta), 4 limbs each, canonical
  * (upstream draws them from algebraic_random_device).  Builds the whole key on the GPU: Lagrange coefficients at t, the
- * per-variable QAP evaluations, the exponent vectors and the six batch exponentiations.  precompute != 0 additionally stores
- * the window multiples of the five proving-key queries (vsp_bases_precompute).  The key owns its queries. */
+ * per-variable QAP evaluations, the exponent vectors and the six batch exponentiations.  precompute additionally stores the window
+ * multiples (vsp_bases_precompute) of proving-key queries: bit 0 = the recommended set (A, both halves of B, L; H stays plain: dense scalars
+ * gain nothing from it and its 2 GB table would miss the cache); bits 1..5 select A_query, B_query (G1), B_query (G2), H_query, L_query one by one.  The key owns its queries. */
 typedef struct vsp_keypair vsp_keypair;
 vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64_t toxic[20], int precompute);
 const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp);

@@ -392,7 +392,7 @@ class Keypair:
         self.ctx = ctx
         if _handle is None:
             toxic = _u64(toxic).reshape(20)
-            _handle = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(bool(precompute)))
+            _handle = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(precompute))      # True = 1 = every query; else a bit mask (vsp.h)
             if not _handle:
                 raise VspError("groth16_generate failed: " + ctx.last_error())
         self.h = _handle
