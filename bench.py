@@ -209,6 +209,25 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
 
 
 
+def host_cores():
+    """CPU cores this process may really use: the cgroup quota where one is set (a GPU box gives a share of its host), else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return min(n, 64)
+
+
 def shard_bounds(total, world, rank):
     """contiguous point chunk of rank `rank`: [lo, hi)"""
     return rank * total // world, (rank + 1) * total // world
@@ -503,7 +522,7 @@ def main():
                             "sample": f"one {m}-point G1 MSM (serial BDLO12 restatement, oracle/vsp_ref.c), {dt:.1f} s",
                             "matches_gpu_result": ok}
             from concurrent.futures import ThreadPoolExecutor
-            cores = len(os.sched_getaffinity(0))
+            cores = host_cores()
             cuts = [shard_bounds(m, cores, i) for i in range(cores)]
             tc = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:             # the C call releases the GIL: one chunk per core
