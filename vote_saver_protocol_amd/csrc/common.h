@@ -68,6 +68,8 @@ struct MsmWork {
 };
 static constexpr unsigned VSP_MSM_SLOTS = 6;
 static constexpr int VSP_MSM_DENSE = -2;      // plan_from_slot value: the scalars are known to be dense, skip the 0/1 census
+static constexpr int VSP_MSM_PLAN_ONLY = -3;  // plan_from_slot value: queue only the digit sort and the bucket plan (up to plan_ready); a later launch on the
+                                              // SAME slot with plan_from_slot = that slot queues the accumulation and the reduction over it
 
 }  // namespace vsp
 

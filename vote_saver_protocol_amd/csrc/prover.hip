@@ -199,10 +199,6 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     VSP_HIP(hipEventRecord(ctx->ev_aux, st));          // z resident and censuses queued
     // option "prove_h_first" (default 1): queue witness_map + H before the witness multi-exponentiations, or after (0)
     long h_first = 1; { auto it = ctx->opts.find("prove_h_first"); if (it != ctx->opts.end()) h_first = it->second; }
-    if (h_first) {
-        VSP_TRY(witness_map_device(ctx, dA, dB, dC, &cs->dom, dH));
-        VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
-    }
     {
         hipStream_t s1, s2, s3, s4;
         VSP_TRY(msm_slot_stream(ctx, 1, &s1)); VSP_TRY(msm_slot_stream(ctx, 2, &s2));
@@ -210,10 +206,24 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
         VSP_HIP(hipStreamWaitEvent(s1, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s2, ctx->ev_aux, 0));
         VSP_HIP(hipStreamWaitEvent(s3, ctx->ev_aux, 0)); VSP_HIP(hipStreamWaitEvent(s4, ctx->ev_aux, 0));
     }
-    VSP_TRY(launch_on_bases(ctx, 1, pk->A, 0, nv + 1, dz, -1));
+    // option "prove_plan_first" (default 0): queue the digit sorts and bucket plans of the two witness vectors BEFORE witness_map.
+    // Their counting sort needs 128 KiB of LDS per workgroup; queued after the transforms it finds every CU's LDS taken by NTT tiles and
+    // then every wave slot taken by the H accumulation, and waits ~2 ms (kernel timeline).  Queued first it runs while the
+    // GPU is idle -- measured: no gain (9.10 against 9.02 ms): the proof is bound by the sum of its kernels, not by that wait.
+    long plan_first = 0; { auto it = ctx->opts.find("prove_plan_first"); if (it != ctx->opts.end()) plan_first = it->second; }
+    int planA = -1, planL = -1;
+    if (h_first && plan_first) {
+        VSP_TRY(launch_on_bases(ctx, 1, pk->A, 0, nv + 1, dz, VSP_MSM_PLAN_ONLY)); planA = 1;
+        VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, VSP_MSM_PLAN_ONLY)); planL = 4;
+    }
+    if (h_first) {
+        VSP_TRY(witness_map_device(ctx, dA, dB, dC, &cs->dom, dH));
+        VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));   // H coefficients are dense
+    }
+    VSP_TRY(launch_on_bases(ctx, 1, pk->A, 0, nv + 1, dz, planA));
     VSP_TRY(launch_on_bases(ctx, 3, pk->B2, 0, nv + 1, dz, pk->B2->pre_c == pk->A->pre_c ? 1 : -1));
     VSP_TRY(launch_on_bases(ctx, 2, pk->B1, 0, nv + 1, dz, pk->B1->pre_c == pk->A->pre_c ? 1 : -1));
-    VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, -1));
+    VSP_TRY(launch_on_bases(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, planL));
     if (!h_first) {
         VSP_TRY(witness_map_device(ctx, dA, dB, dC, &cs->dom, dH));
         VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));
