@@ -277,6 +277,93 @@ __device__ __forceinline__ void mont_mul28x2_asm(uint32_t *r, const uint32_t *a,
 }}
 """
 
+# ---------------------------------------------------------------- carry-free 9 x 29-bit product for Fr (R' = 2^261): the NTT butterflies
+R255 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+N29, W29 = 9, 29
+MASK29 = (1 << W29) - 1
+
+
+def limbs29(v):
+    return [(v >> (W29 * i)) & MASK29 for i in range(N29 - 1)] + [v >> (W29 * (N29 - 1))]
+
+
+def body29():
+    """The 28-bit scheme for Fr: a column is 9 + 9 products below 2^60 (operand limb bounds 2^Ea, 2^Eb with Ea + Eb <= 60: a twiddle is
+    tight, 29 bits, so a data operand may have limbs up to 2^31), one 64-bit accumulator, no carries.  r = 1 mod 2^32, so -1/r = -1
+    mod 2^29 and m_k is a negation and a mask instead of a multiplication.  Output: limbs below 2^29 (top limb the rest), value below
+    a*b / 2^261 + r; a and b are preserved.  Register map: a v0..8, b v9..17, m / result v18..26, temp v27, accumulator v[28:29];
+    s0..s8 = r's limbs, s9 = mask."""
+    A = lambda i: f"v{i}"
+    B = lambda i: f"v{N29 + i}"
+    M = lambda i: f"v{2 * N29 + i}"
+    Pm = lambda i: f"s{i}"
+    MSK = "s9"
+    base = 3 * N29 + 1                    # 64-bit register pairs must start at an even register on gfx950: v[28:29]; temp v27
+    lo, hi, pr, tmp = f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]", f"v{base - 1}"
+    ins = [f"v_mov_b32 {lo}, 0", f"v_mov_b32 {hi}, 0"]
+    for k in range(2 * N29 - 1):
+        for i in range(max(0, k - N29 + 1), min(k, N29 - 1) + 1):
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {A(i)}, {B(k - i)}, {pr}")
+        for i in (range(0, k) if k < N29 else range(k - N29 + 1, N29)):
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {M(i)}, {Pm(k - i)}, {pr}")
+        if k < N29:
+            ins.append(f"v_sub_u32 {tmp}, 0, {lo}")                      # m_k = -lo mod 2^29
+            ins.append(f"v_and_b32 {M(k)}, {MSK}, {tmp}")
+            ins.append(f"v_mad_u64_u32 {pr}, vcc, {M(k)}, {Pm(0)}, {pr}")
+        else:
+            ins.append(f"v_and_b32 {M(k - N29)}, {MSK}, {lo}")
+        ins.append(f"v_lshrrev_b64 {pr}, {W29}, {pr}")
+    ins.append(f"v_mov_b32 {M(N29 - 1)}, {lo}")
+    return ins
+
+
+def redundant29(c, lend):
+    k = limbs29(c * R255)
+    out = [k[0] + lend * (1 << W29)] + [k[i] + lend * (1 << W29) - lend for i in range(1, N29 - 1)] + [k[N29 - 1] - lend]
+    assert sum(x << (W29 * i) for i, x in enumerate(out)) == c * R255 and all(0 <= x < (1 << 32) for x in out)
+    return out
+
+
+def gen29():
+    r29 = limbs29(R255)
+    assert (-pow(R255, -1, 1 << W29)) % (1 << W29) == MASK29
+    ins = body29()
+    lines = ['s_branch .Lvsp_mm29_end', '.p2align 8', 'vsp_mm29:']
+    lines += [f's_mov_b32 s{i}, 0x{r29[i]:x}' for i in range(N29)] + [f's_mov_b32 s9, 0x{MASK29:x}']
+    lines += ins + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm29_end:']
+    body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
+    vclob = ", ".join(f'"v{i}"' for i in range(3 * N29 + 3))
+    sclob = ", ".join(f'"s{i}"' for i in range(10))
+    n_mad = sum(1 for x in ins if x.startswith("v_mad"))
+    arr = lambda name, v: f"static constexpr uint32_t {name}[9] = {{" + ", ".join(f"0x{x:x}u" for x in v) + "};"
+    R1 = (1 << 261) % R255
+    consts = "\n".join([arr("FR29_R", r29), arr("FR29_ONE", limbs29(R1)), arr("FR29_R2", limbs29(R1 * R1 % R255)),
+                        arr("FR29_K2_L1", redundant29(2, 1)), arr("FR29_K4_L1", redundant29(4, 1))])
+    outs = ", ".join(f'"={{v{2 * N29 + i}}}"(r[{i}])' for i in range(N29))
+    inps = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N29)] + [f'"{{v{N29 + i}}}"(b[{i}])' for i in range(N29)])
+    return f"""// ---- Fr on 9 x 29-bit limbs, R' = 2^261: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v29 ----
+// constants: r; R' mod r (the Montgomery one); R'^2 mod r; 2r and 4r in the redundant form of the lazy subtractions
+{consts}
+template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul29_holder() {{
+    asm volatile(
+{body_txt}
+        :
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclob});
+}}
+// r = a*b*2^(-261) mod r as described at body29(); a and b are preserved
+__device__ __forceinline__ void mont_mul29_asm(uint32_t *r, const uint32_t *a, const uint32_t *b) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, vsp_mm29@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, vsp_mm29@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outs}
+        : {inps}
+        : "vcc", "scc", "s30", "s31", {sclob}, "v27", "v28", "v29");
+}}
+"""
+
+
 def main():
     text = '''// GENERATED by tools/gen_mont_asm.py -- do not edit.  See that file for the design notes.
 #pragma once
@@ -284,7 +371,7 @@ def main():
 
 namespace vsp {
 
-''' + gen(12) + "\n" + gen(8) + "\n" + gen28() + "\n}  // namespace vsp\n"
+''' + gen(12) + "\n" + gen(8) + "\n" + gen28() + "\n" + gen29() + "\n}  // namespace vsp\n"
     open(OUT, "w").write(text)
     print("wrote", os.path.normpath(OUT))
 

@@ -133,6 +133,7 @@ void vsp_destroy(vsp_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch, &ctx->dom_scratch,
+                      &ctx->ntt.fwd29, &ctx->ntt.inv29, &ctx->ntt.pw29[0], &ctx->ntt.pw29[1], &ctx->ntt.pw29[2], &ctx->ntt.pw29[3],
                       &ctx->msm_scalars, &ctx->val_flag, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
                       &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
     for (DevBuf *b : bufs) free_buf(*b);

@@ -28,6 +28,10 @@ struct NttTables {
     unsigned pw_log = 0;    // log_m the hi tables were sized for
     uint64_t pw_g[4] = {0, 0, 0, 0};
     bool pw_valid = false;
+    // the same tables for the 9 x 29-bit butterflies (fr29.h): Montgomery form for R' = 2^261, three planes per table (16 + 16 + 4 bytes per entry)
+    DevBuf fwd29, inv29, pw29[4];   // pw29: lo_f, hi_f, lo_i, hi_i
+    unsigned log29 = 0;             // log the fwd29 / inv29 tables were converted for (0 = none)
+    unsigned pw29_log = 0; uint64_t pw29_g[4] = {0, 0, 0, 0}; bool pw29_valid = false;
 };
 
 // digit-window geometry of one MSM

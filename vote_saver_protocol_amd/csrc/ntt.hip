@@ -25,6 +25,7 @@
 //    first pass's load / the last pass's store.
 //  * The path is integer-ALU bound (one 8-limb Montgomery product per butterfly), not HBM bound.
 #include "common.h"
+#include "fr29.h"
 
 namespace vsp {
 
@@ -151,6 +152,137 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(const Fr *__restrict__
     }
 }
 
+// ================================================================================================
+// The same pass on 9 x 29-bit limbs with lazy reduction (fr29.h): ~1.4 x fewer instructions per butterfly.  Data enters canonical
+// (8 x 32-bit words), stays "lazy" (congruent, tight limbs, value below 48 r) in LDS and -- between passes -- in the scratch buffer
+// (three planes: limbs 0-3, limbs 4-7, limb 8: 36 bytes per element), and leaves canonical from the last pass, where the product
+// with the scale (1/m, the extra scale, the inverse coset power -- or the Montgomery one when there is none) brings it below 2r.
+// Twiddles and coset powers come from tables in Montgomery form for R' = 2^261, canonical, in the same three planes.
+struct Planes29 { const uint4 *p0, *p1; const uint32_t *p2; };
+struct PlanesOut29 { uint4 *p0, *p1; uint32_t *p2; };
+struct NttPass29Args {
+    unsigned log_n, s0, s1, clog, tlog;
+    int first, last, premul, postmul;
+    Planes29 tw, pw_lo, pw_hi;
+    Fr29 scale;             // Montgomery (R') form, canonical; the Montgomery one when no scaling is asked for
+};
+__device__ __forceinline__ Fr29 ld29(const Planes29 &t, size_t j) {
+    Fr29 v; uint4 a = t.p0[j], b = t.p1[j];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w; v.l[8] = t.p2[j];
+    return v;
+}
+__device__ __forceinline__ Fr29 lds_load29(const uint4 *pl0, const uint4 *pl1, const uint32_t *pl2, unsigned e) {
+    Fr29 v; uint4 a = pl0[e], b = pl1[e];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w; v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w; v.l[8] = pl2[e];
+    return v;
+}
+__device__ __forceinline__ void lds_store29(uint4 *pl0, uint4 *pl1, uint32_t *pl2, unsigned e, const Fr29 &v) {
+    pl0[e] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    pl1[e] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    pl2[e] = v.l[8];
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(const Fr *__restrict__ in_words, Planes29 in_lazy, Fr *__restrict__ out_words, PlanesOut29 out_lazy,
+                                                            NttPass29Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint4 lds[2u << NTT_TILE_LOG];
+    __shared__ uint32_t lds8[1u << NTT_TILE_LOG];
+    const unsigned K = p.s1 - p.s0;
+    const unsigned C = 1u << p.clog;
+    const unsigned tile = 1u << (K + p.clog);
+    uint4 *pl0 = lds, *pl1 = lds + tile;
+    uint32_t *pl2 = lds8;
+    const unsigned tid = threadIdx.x;
+    const unsigned wg = blockIdx.x;
+    const unsigned lo_bits = p.s0 - p.clog;                   // only meaningful when !first
+    const unsigned lo_hi = p.first ? 0u : (wg & ((1u << lo_bits) - 1u));
+    const unsigned hi = p.first ? 0u : (wg >> lo_bits);
+    const size_t base_pos = p.first ? 0 : (((size_t)hi << p.s1) | ((size_t)lo_hi << p.clog));
+
+    // ---- load tile
+    for (unsigned e = tid; e < tile; e += NTT_THREADS) {
+        unsigned mid = e >> p.clog, c = e & (C - 1);
+        size_t src;
+        if (p.first) src = ((size_t)brev(mid, p.s1) << (p.log_n - p.s1)) + (size_t)wg * C + c;
+        else src = base_pos | ((size_t)mid << p.s0) | c;
+        Fr29 v;
+        if (p.first) {
+            v = fr29_from_words(in_words[src]);
+            if (p.premul) v = mul29(v, mul29(ld29(p.pw_lo, src & ((1u << PW_LOG) - 1u)), ld29(p.pw_hi, src >> PW_LOG)));
+        } else v = ld29(in_lazy, src);
+        lds_store29(pl0, pl1, pl2, e, v);
+    }
+    __syncthreads();
+
+    const unsigned lo_part = p.first ? 0u : ((lo_hi << p.clog));
+    unsigned t = 0;
+    if (K & 1) {
+        const unsigned s = p.s0;
+        for (unsigned bf = tid; bf < (tile >> 1); bf += NTT_THREADS) {
+            unsigned c = bf & (C - 1), q = bf >> p.clog;
+            unsigned e0 = (q << (1 + p.clog)) | c, e1 = e0 + C;
+            Fr29 u = lds_load29(pl0, pl1, pl2, e0), v = lds_load29(pl0, pl1, pl2, e1);
+            if (s > 0) v = mul29(v, ld29(p.tw, (size_t)(p.first ? 0u : (lo_part | c)) << (p.tlog - 1 - s)));
+            lds_store29(pl0, pl1, pl2, e0, norm29(add29(u, v)));
+            lds_store29(pl0, pl1, pl2, e1, norm29(sub29(u, v)));       // s == 0 only in the first pass: v is a canonical input there
+        }
+        __syncthreads();
+        t = 1;
+    }
+    for (; t < K; t += 2) {
+        const unsigned s = p.s0 + t;
+        const unsigned h = 1u << t;
+        for (unsigned g = tid; g < (tile >> 2); g += NTT_THREADS) {
+            unsigned c = g & (C - 1), q = g >> p.clog;
+            unsigned mid_lo = q & (h - 1);
+            unsigned mid0 = ((q >> t) << (t + 2)) | mid_lo;
+            unsigned e0 = (mid0 << p.clog) | c, e1 = e0 + (h << p.clog), e2 = e1 + (h << p.clog), e3 = e2 + (h << p.clog);
+            const size_t off = p.first ? 0u : (lo_part | c);
+            Fr29 x0 = lds_load29(pl0, pl1, pl2, e0), x1 = lds_load29(pl0, pl1, pl2, e1), x2 = lds_load29(pl0, pl1, pl2, e2), x3 = lds_load29(pl0, pl1, pl2, e3);
+            if (s > 0) {
+                const Fr29 w1 = ld29(p.tw, (((size_t)mid_lo << p.s0) | off) << (p.tlog - 1 - s));
+                x1 = mul29(x1, w1); x3 = mul29(x3, w1);
+            }
+            Fr29 a0 = add29(x0, x1), a1 = sub29(x0, x1), a2 = add29(x2, x3), a3 = sub29(x2, x3);
+            a2 = mul29(a2, ld29(p.tw, (((size_t)mid_lo << p.s0) | off) << (p.tlog - 2 - s)));
+            a3 = mul29(a3, ld29(p.tw, (((size_t)(mid_lo + h) << p.s0) | off) << (p.tlog - 2 - s)));
+            lds_store29(pl0, pl1, pl2, e0, norm29(add29(a0, a2)));
+            lds_store29(pl0, pl1, pl2, e1, norm29(add29(a1, a3)));
+            lds_store29(pl0, pl1, pl2, e2, norm29(sub29(a0, a2)));
+            lds_store29(pl0, pl1, pl2, e3, norm29(sub29(a1, a3)));
+        }
+        __syncthreads();
+    }
+
+    // ---- store tile
+    for (unsigned i = tid; i < tile; i += NTT_THREADS) {
+        unsigned mid, c; size_t pos;
+        if (p.first) { mid = i & ((1u << K) - 1u); c = i >> K; pos = ((size_t)brev(wg * C + c, p.log_n - p.s1) << p.s1) | mid; }
+        else { mid = i >> p.clog; c = i & (C - 1); pos = base_pos | ((size_t)mid << p.s0) | c; }
+        Fr29 v = lds_load29(pl0, pl1, pl2, (mid << p.clog) | c);
+        if (p.last) {
+            Fr29 m = p.scale;
+            if (p.postmul == 2) m = mul29(m, mul29(ld29(p.pw_lo, pos & ((1u << PW_LOG) - 1u)), ld29(p.pw_hi, pos >> PW_LOG)));
+            out_words[pos] = fr29_to_words(csub29(mul29(v, m)));
+        } else {
+            out_lazy.p0[pos] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+            out_lazy.p1[pos] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+            out_lazy.p2[pos] = v.l[8];
+        }
+    }
+#endif
+}
+
+// 8 x 32-bit Montgomery table -> three planes in the R' = 2^261 form
+__global__ __launch_bounds__(256) void k_table29(const Fr *in, size_t count, uint4 *p0, uint4 *p1, uint32_t *p2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr29 v = fr29_from_mont256(in[j]);
+    p0[j] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]); p1[j] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]); p2[j] = v.l[8];
+#endif
+}
+
 // T[j] = A[j & 2047] * B[j >> 11]  (all Montgomery)
 __global__ __launch_bounds__(256) void k_fill_twiddles(Fr *T, const Fr *A, const Fr *B, size_t count) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +338,7 @@ int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m) {
     VSP_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(lo.p); hipFree(hi.p);
     t.log = lg;
+    t.log29 = 0;                 // the 29-bit copies follow on demand (ntt29_ensure_tables)
     return VSP_OK;
 }
 
@@ -218,7 +351,57 @@ int ntt_ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4) {
     VSP_TRY(upload_power_tables(ctx, g, hi_count, t.pw_lo_f, t.pw_hi_f));
     VSP_TRY(upload_power_tables(ctx, inv(g), hi_count, t.pw_lo_i, t.pw_hi_i));
     memcpy(t.pw_g, g4, 32); t.pw_log = log_m; t.pw_valid = true;
+    t.pw29_valid = false;
     return VSP_OK;
+}
+
+// the three planes of a 29-bit table of `count` entries stored at `base`
+static Planes29 planes_of(const DevBuf &b, size_t count) {
+    Planes29 pl; pl.p0 = (const uint4 *)b.p; pl.p1 = (const uint4 *)((const char *)b.p + 16 * count); pl.p2 = (const uint32_t *)((const char *)b.p + 32 * count);
+    return pl;
+}
+static int convert_table29(vsp_ctx *ctx, const DevBuf &src, size_t count, DevBuf &dst) {
+    VSP_TRY(ensure(ctx, dst, 36 * count));
+    hipLaunchKernelGGL(k_table29, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr *)src.p, count,
+                       (uint4 *)dst.p, (uint4 *)((char *)dst.p + 16 * count), (uint32_t *)((char *)dst.p + 32 * count));
+    VSP_LAUNCH_CHECK();
+    return VSP_OK;
+}
+// 29-bit copies of the twiddle tables (and of the coset power tables when a coset generator is in use), converted on the GPU
+static int ntt29_ensure_tables(vsp_ctx *ctx, bool coset) {
+    NttTables &t = ctx->ntt;
+    if (t.log29 != t.log) {
+        const size_t count = (size_t)1 << (t.log - 1);
+        VSP_TRY(convert_table29(ctx, t.fwd, count, t.fwd29));
+        VSP_TRY(convert_table29(ctx, t.inv, count, t.inv29));
+        t.log29 = t.log;
+    }
+    if (coset && !(t.pw29_valid && t.pw29_log == t.pw_log && memcmp(t.pw29_g, t.pw_g, 32) == 0)) {
+        const size_t L = (size_t)1 << PW_LOG, n = (size_t)1 << t.pw_log, H = n > L ? (n >> PW_LOG) : 1;
+        VSP_TRY(convert_table29(ctx, t.pw_lo_f, L, t.pw29[0])); VSP_TRY(convert_table29(ctx, t.pw_hi_f, H, t.pw29[1]));
+        VSP_TRY(convert_table29(ctx, t.pw_lo_i, L, t.pw29[2])); VSP_TRY(convert_table29(ctx, t.pw_hi_i, H, t.pw29[3]));
+        memcpy(t.pw29_g, t.pw_g, 32); t.pw29_log = t.pw_log; t.pw29_valid = true;
+    }
+    return VSP_OK;
+}
+static Fr29 host_to_fr29_mont(const HFr &x) {          // host value (Montgomery, R = 2^256) -> canonical x * 2^261 mod r as 9 x 29-bit limbs
+    uint64_t c[4]; host_store_canon(c, x);
+    HFr sh = host_load_canon<HFr>(c);                   // x again, to multiply by 2^261 = 2^256 * 2^5 through host arithmetic
+    HFr two = add(HFr::one(), HFr::one()), p32 = two;
+    for (int i = 0; i < 4; i++) p32 = add(p32, p32);      // 2^5
+    // 2^256 mod r in Montgomery form is R^2's reduction: to_mont(one's canonical R)...: simpler: multiply by 2 two hundred sixty-one times
+    HFr acc = sh;
+    for (int i = 0; i < 261; i++) acc = add(acc, acc);
+    host_store_canon(c, acc);
+    Fr29 r;
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 6, s2 = bit & 63;
+        unsigned __int128 v = c[w];
+        if (w + 1 < 4) v |= (unsigned __int128)c[w + 1] << 64;
+        r.l[i] = (uint32_t)(v >> s2) & (i < 8 ? 0x1FFFFFFFu : 0xFFFFFFFFu);
+    }
+    (void)p32;
+    return r;
 }
 
 // d_a: n canonical Fr values in device memory, transformed in place.
@@ -243,13 +426,47 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
             for (unsigned k = i + 1; k < npass; k++)
                 if ((stages[k] & 1) && stages[i] < NTT_MAX_STAGES && stages[k] > 1) { stages[i]++; stages[k]--; break; }
 
+    long use29 = 1; { auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) use29 = it->second; }
     Fr *scratch = nullptr;
-    if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * sizeof(Fr))); scratch = (Fr *)ctx->ntt_scratch.p; }
+    if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * (use29 ? 36 : sizeof(Fr)))); scratch = (Fr *)ctx->ntt_scratch.p; }
 
     HFr scale = HFr::one();
     bool have_scale = false;
     if (inverse) { scale = inv(host_from_u64((uint64_t)n)); have_scale = true; }
     if (extra_scale) { scale = mul(scale, *extra_scale); have_scale = true; }
+
+    if (use29) {
+        // butterflies on 9 x 29-bit limbs (fr29.h); the scratch buffer holds lazy values in three planes between passes
+        VSP_TRY(ntt29_ensure_tables(ctx, coset_g != nullptr));
+        const size_t tcount = (size_t)1 << (ctx->ntt.log - 1);
+        const size_t L = (size_t)1 << PW_LOG, pn = (size_t)1 << ctx->ntt.pw_log, H = pn > L ? (pn >> PW_LOG) : 1;
+        Planes29 lazy_in = planes_of(ctx->ntt_scratch, n);
+        PlanesOut29 lazy_out; lazy_out.p0 = (uint4 *)lazy_in.p0; lazy_out.p1 = (uint4 *)lazy_in.p1; lazy_out.p2 = (uint32_t *)lazy_in.p2;
+        unsigned s0 = 0;
+        for (unsigned i = 0; i < npass; i++) {
+            NttPass29Args p;
+            memset(&p, 0, sizeof p);
+            p.log_n = log_m; p.s0 = s0; p.s1 = s0 + stages[i];
+            p.tlog = ctx->ntt.log;
+            p.first = (i == 0); p.last = (i == npass - 1);
+            p.clog = npass == 1 ? 0 : NTT_TILE_LOG - stages[i];
+            p.tw = planes_of(inverse ? ctx->ntt.inv29 : ctx->ntt.fwd29, tcount);
+            p.premul = (p.first && coset_g && !inverse) ? 1 : 0;
+            p.postmul = (p.last && inverse && coset_g) ? 2 : 1;                    // the last pass always multiplies: by the scale or by one
+            if (p.premul) { p.pw_lo = planes_of(ctx->ntt.pw29[0], L); p.pw_hi = planes_of(ctx->ntt.pw29[1], H); }
+            if (p.postmul == 2) { p.pw_lo = planes_of(ctx->ntt.pw29[2], L); p.pw_hi = planes_of(ctx->ntt.pw29[3], H); }
+            p.scale = host_to_fr29_mont(scale);
+            if (!p.first && p.s0 < p.clog) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: pass plan");
+            const unsigned tile_log = stages[i] + p.clog;
+            hipLaunchKernelGGL(k_ntt29_pass, dim3((unsigned)(n >> tile_log)), dim3(NTT_THREADS), 0, ctx->stream, (const Fr *)d_a, lazy_in, d_a, lazy_out, p);
+            VSP_LAUNCH_CHECK();
+            s0 = p.s1;
+        }
+        ctx->stats["ntt_passes"] = (double)npass;
+        ctx->stats["ntt_fr29"] = 1;
+        return VSP_OK;
+    }
+    ctx->stats["ntt_fr29"] = 0;
 
     unsigned s0 = 0;
     for (unsigned i = 0; i < npass; i++) {
