@@ -350,6 +350,8 @@ def main():
         ctx.set_option("msm_window_bits", args.window_bits)
     if os.environ.get("VSP_MSM_SPLIT"):
         ctx.set_option("msm_split", int(os.environ["VSP_MSM_SPLIT"]))      # experiment knob: points per bucket part
+    if os.environ.get("VSP_MSM_GLV"):
+        ctx.set_option("msm_glv", int(os.environ["VSP_MSM_GLV"]))          # experiment knob: 2 forces the endomorphism split at any size
     if args.prove_h_first >= 0:
         ctx.set_option("prove_h_first", args.prove_h_first)
     depth = 1 if args.no_pipeline else args.pipeline_depth
@@ -404,6 +406,7 @@ def main():
 
     def roofline_of(group, n_points, windows, excl_ms, excl_step_ms, pipe_ms):
         """HBM line (the contract's) and the v_mad_u64_u32 issue line (the bound that applies) for one accumulation launch"""
+        split = int(ctx.stat("msm_endomorphism_split"))       # endomorphism split: 2n half-length scalars over `windows` windows
         bytes_alg = n_points * BYTES_PER_PAIR[group]
         achieved = bytes_alg / (excl_ms * 1e-3) / 1e9
         traffic, src = None, None
@@ -418,7 +421,7 @@ def main():
                     break
                 except Exception:
                     continue
-        mads = n_points * windows * MADS_PER_ADD[group]
+        mads = n_points * (2 if split else 1) * windows * MADS_PER_ADD[group]
         rl = {"bound": "hbm", "kernel": "k_accum28 (bucket accumulation on 14 x 28-bit limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
               "traffic_over_algorithmic": (traffic / bytes_alg) if traffic else None,
@@ -430,7 +433,7 @@ def main():
                       "not measurable in-process (PMC passes need rocprofv3): it is read from traffic_source"}
         rv = {"bound": "v_mad_u64_u32 issue", "kernel": rl["kernel"], "achieved": mads / (excl_ms * 1e-3) / 1e12, "peak": VALU_PEAK_MADS / 1e12,
               "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads / (excl_ms * 1e-3) / VALU_PEAK_MADS, "mads_per_mixed_addition": MADS_PER_ADD[group],
-              "mixed_additions_per_launch": n_points * windows, "peak_source": "profiles/r1_ubench_valu.txt (tools/ubench_valu.hip, measured on MI355X)"}
+              "mixed_additions_per_launch": n_points * (2 if split else 1) * windows, "endomorphism_split": bool(split), "peak_source": "profiles/r1_ubench_valu.txt (tools/ubench_valu.hip, measured on MI355X)"}
         return rl, rv
 
     extras = {}
@@ -645,11 +648,13 @@ def main():
         "dtype": "u32",          # 32-bit registers: 28-bit limbs, 32x32->64-bit multiply-add: exact integer Montgomery arithmetic (381-bit Fp, 255-bit Fr)
         "data": "synthetic",
         "config": {"workload": (f"2^{args.log_n}-point BLS12-381 G1 Pippenger MSM per GPU, " +
-                                ("resident key WITH the 16x table of window multiples, " if args.precompute else "PLAIN bases k_i*G (no precomputed table), ") +
+                                ("resident key WITH the 16x table of window multiples, " if args.precompute else
+                                 "PLAIN bases k_i*G (no table of window multiples; the library's 28-bit-limb copy keeps phi(P) = (beta x, y) beside every P for the endomorphism split), ") +
                                 f"uniform scalars, bases and scalars resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
                                 "RCCL all-gather of Jacobian partial sums + fold"),
                    "points_per_gpu": n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth,
-                   "bases_precomputed_window_multiples": bool(args.precompute), "bases_memory_factor": 16 if args.precompute else 1,
+                   "bases_precomputed_window_multiples": bool(args.precompute),
+                   "bases_memory_bytes_per_point": (16 * (96 + 128)) if args.precompute else (96 + 2 * 128),
                    "precompute_once_s": precompute_s},
         "verified_bit_exact": verified,
         "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3,

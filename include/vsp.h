@@ -62,9 +62,9 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * "msm_census_sync" (1: every multi-exponentiation waits for its own 0/1 census before planning; default 0: a slot plans from the
  * count it saw for the previous vector of the same length -- the count steers window size and part length, never the result);
  * "msm_glv" (default 1: plain resident bases keep phi(P) = (beta x, y) = lambda P beside every P in the 28-bit-limb table -- 2 x 128
- * (G1) / 2 x 256 (G2) bytes per point -- and every scalar is split k = k1 + k2 lambda into two 128-bit halves: half as many windows,
- * i.e. half the bucket sets to reduce -- applied while the doubled table stays within 64 MB (up to 2^18 G1 / 2^17 G2 points:
- * beyond that the larger table costs the accumulation more cache misses than the bucket reduction saves); 2 forces it for any size, 0 before an upload keeps the plain layout);
+ * (G1) / 2 x 256 (G2) bytes per point -- and every scalar is split k = k1 + k2 lambda into two signed 127-bit halves: half as many windows,
+ * i.e. half the bucket sets to reduce -- applied while the doubled table stays within 256 MB for G1 (2^20 points) / 128 MB for G2
+ * (2^18 points): beyond that the measurements favour the plain layout; 2 forces it for any size, 0 before an upload keeps the plain layout);
  * tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
  * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
  * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the

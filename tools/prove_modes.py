@@ -8,6 +8,8 @@ import vote_saver_protocol_amd as v
 lg = int(os.environ.get("LOG_M", "20"))
 ni = 30; nc = (1 << lg) - ni - 2
 ctx = v.Context(0)
+if os.environ.get("VSP_MSM_GLV"):
+    ctx.set_option("msm_glv", int(os.environ["VSP_MSM_GLV"]))
 gen = o.splitmix64(5)
 cs, wit = cref.R1CS.synth(nc, ni, 4, ballot=(25, 7))
 tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)

@@ -262,12 +262,14 @@ static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
     long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
     const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
-    // The split halves the bucket sets but doubles the table.  Measured (tools/msm_sizes.py, blocking / three in flight, ms): G1 2^16
-    // 1.48 / 1.37 -> 1.26 / 0.77, G1 2^18 2.30 / 1.29 -> 2.05 / 1.23, G2 2^16 2.99 / 1.48 -> 2.55 / 1.36 -- but G1 2^19 2.82 -> 3.09 and
-    // G1 2^20: the 256 MB interleaved table no longer sits in the Infinity Cache beside the sort's arrays and one accumulation goes
-    // from 2.62 to 3.22 ms, more than the bucket reduction gives back.  So: on while the doubled table is at most 64 MB (2^18 G1 /
-    // 2^17 G2 points -- the size class of the reference's real circuit); "msm_glv" = 2 forces it on.
-    const bool glv = want_glv && b->pre_c == 0 && count < ((size_t)1 << 30) && (want_glv >= 2 || 2 * count * row <= ((size_t)64 << 20));
+    // The split halves the bucket sets (and the host Horner chain) but doubles the table and the sort's input.  Measured
+    // (tools/msm_sizes.py, bench.py; one in flight / three in flight, ms): G1 2^16 1.49 / 1.42 -> 1.35 / 0.80, G1 2^18 2.31 / 1.29 ->
+    // 2.04 / 1.27, G1 2^20 4.24 / 3.35 -> 3.98 / 3.34, a 2^20-constraint proof 8.71 -> 8.45 ms (plain key: 9.98 -> 8.95);
+    // G2 2^16 3.01 / 1.58 -> 2.67 / 1.40, G2 2^18 5.21 / 3.21 -> 5.56 / 2.90, G2 2^19 7.23 / 4.82 -> 8.28 / 5.58 (dense scalars:
+    // the lane-pair merges of the split buckets cost more than the windows saved).  So: on while the doubled table is at most
+    // 256 MB for G1 (2^20 points) and 128 MB for G2 (2^18 points); "msm_glv" = 2 forces it on, 0 switches it off.
+    const size_t glv_limit = b->group == 1 ? ((size_t)256 << 20) : ((size_t)128 << 20);
+    const bool glv = want_glv && b->pre_c == 0 && count < ((size_t)1 << 30) && (want_glv >= 2 || 2 * count * row <= glv_limit);
     void *t28 = nullptr;
     if (!want || hipMalloc(&t28, count * row * (glv ? 2 : 1)) != hipSuccess) { hipGetLastError(); return; }
     int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28, glv) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28, glv);
