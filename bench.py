@@ -565,13 +565,24 @@ def main():
             dtn = (time.perf_counter() - tn) / reps
             extras["ntt_2p22_ms"] = dtn * 1e3
             extras["ntt_2p22_elements_per_s"] = (1 << lg) / dtn
+            tn = time.perf_counter()
+            for _ in range(reps):
+                dom.fft_device(a, inverse=True)
+            ctx.synchronize()
+            extras["ntt_2p22_inverse_ms"] = (time.perf_counter() - tn) / reps * 1e3
             # algorithmic bytes = 64 B per element for the whole transform (one ideal read + write); the kernel makes
-            # `passes` round trips through HBM, each reading and writing every element once
-            npass = int(ctx.stat("ntt_passes"))
-            extras["roofline_ntt_2p22"] = {"bound": "hbm", "kernel": "k_ntt_pass (all passes of one transform)", "achieved": (1 << lg) * 64 / dtn / 1e9,
-                                           "peak": 8000.0, "unit": "GB/s", "frac": (1 << lg) * 64 / dtn / 1e9 / 8000.0, "passes": npass,
-                                           "actual_bytes_moved": npass * (1 << lg) * 64, "per_pass_GBs": (1 << lg) * 64 / (dtn / npass) / 1e9,
-                                           "note": "integer-VALU bound: 11 Fr products per element; see DESIGN.md 3.2 for the measured split"}
+            # `passes` round trips through HBM: the first reads 32 B and writes 36 B per element (lazy 9 x 29-bit limbs), the middle ones
+            # read and write 36 B, the last reads 36 B and writes 32 B
+            npass = int(ctx.stat("ntt_passes")); f29 = bool(ctx.stat("ntt_fr29"))
+            moved = (1 << lg) * ((32 + 36) * 2 + 72 * (npass - 2)) if (f29 and npass > 1) else npass * (1 << lg) * 64
+            # VALU line: 11 products of 162 v_mad_u64_u32 per element (plus one to leave the lazy domain) against the measured issue peak
+            mads = (1 << lg) * (lg / 2.0 + 1) * 162 if f29 else (1 << lg) * (lg / 2.0) * 128
+            extras["roofline_ntt_2p22"] = {"bound": "hbm", "kernel": ("k_ntt29_pass" if f29 else "k_ntt_pass") + " (all passes of one forward transform)",
+                                           "achieved": (1 << lg) * 64 / dtn / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": (1 << lg) * 64 / dtn / 1e9 / 8000.0,
+                                           "passes": npass, "actual_bytes_moved": moved, "butterflies_on_29_bit_limbs": f29,
+                                           "valu_frac_of_mad_issue_peak": mads / dtn / VALU_PEAK_MADS,
+                                           "note": "integer-VALU bound: 11 Fr products per element (22 stages as radix-4 steps); the mads alone are a third of the "
+                                                   "instructions of a butterfly; see DESIGN.md 3.2"}
             del a
             n2 = 1 << 18
             k2, s2 = rand_fr(n2, 11), rand_fr(n2, 12)
