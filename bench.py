@@ -404,9 +404,9 @@ def main():
         ms, launches = ctx.stat("msm_accum_ms"), ctx.stat("msm_accum_launches")
         return (ms / launches) if launches else float("nan")
 
-    def roofline_of(group, n_points, windows, excl_ms, excl_step_ms, pipe_ms):
-        """HBM line (the contract's) and the v_mad_u64_u32 issue line (the bound that applies) for one accumulation launch"""
-        split = int(ctx.stat("msm_endomorphism_split"))       # endomorphism split: 2n half-length scalars over `windows` windows
+    def roofline_of(group, n_points, windows, excl_ms, excl_step_ms, pipe_ms, split):
+        """HBM line (the contract's) and the v_mad_u64_u32 issue line (the bound that applies) for one accumulation launch;
+        split: the endomorphism split was on (2n half-length scalars over `windows` windows)"""
         bytes_alg = n_points * BYTES_PER_PAIR[group]
         achieved = bytes_alg / (excl_ms * 1e-3) / 1e9
         traffic, src = None, None
@@ -450,7 +450,7 @@ def main():
         elapsed, result = run_sharded(prob, args.steps, args.warmup, exchange, barrier, depth)
         elapsed = allmax(elapsed)
         pipe_ms = accum_stats()
-        main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
+        main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
         ctx.stats_reset()
         ex_steps = max(2, args.steps // 4)
         ex_elapsed, _ = run_sharded(prob, ex_steps, 1, exchange, barrier, 1)
@@ -459,7 +459,7 @@ def main():
         e_tot = gather_e(prob.e_local)
         if rank == 0:
             verified = bool(np.array_equal(result, expected_point(group, e_tot)))
-        rl, rv = roofline_of(group, prob.n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms)
+        rl, rv = roofline_of(group, prob.n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
         out = {"metric": f"{args.group.upper()} MSM points/sec, one 2^{lg_total}-point problem sharded over the GPUs (BASELINE config 5)",
                "value": total * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -498,7 +498,7 @@ def main():
     elapsed, result = run_sharded(head, args.steps, args.warmup, exchange, barrier, depth)
     elapsed = allmax(elapsed)
     pipe_ms = accum_stats()
-    main_c, main_w = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows"))
+    main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
     # the same MSM with ONE in flight: latency of a single multi-exponentiation and the exclusive duration of its accumulation kernel
     ctx.stats_reset()
     ex_steps = max(4, args.steps // 2)
@@ -644,7 +644,7 @@ def main():
             prob.free()
         extras["config5"] = c5
 
-    rl, rv = roofline_of(1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms)
+    rl, rv = roofline_of(1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
     out = {
         "metric": "G1 MSM points/sec at 2^20 (Groth16 prover hot path)",
         "value": n * world * args.steps / elapsed,
@@ -663,7 +663,7 @@ def main():
                                  "PLAIN bases k_i*G (no table of window multiples; the library's 28-bit-limb copy keeps phi(P) = (beta x, y) beside every P for the endomorphism split), ") +
                                 f"uniform scalars, bases and scalars resident in HBM; N ranks = one 2^{args.log_n}*N-point MSM sharded by contiguous chunk, "
                                 "RCCL all-gather of Jacobian partial sums + fold"),
-                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth,
+                   "points_per_gpu": n, "window_bits": main_c, "windows": main_w, "endomorphism_split": bool(main_split), "msms_in_flight": depth,
                    "bases_precomputed_window_multiples": bool(args.precompute),
                    "bases_memory_bytes_per_point": (16 * (96 + 128)) if args.precompute else (96 + 2 * 128),
                    "precompute_once_s": precompute_s},
