@@ -6,7 +6,7 @@ the bounds in comments; a wrong bound would be a silent soundness bug in a prove
 constants parsed from the generated header the kernels are built from:
 
  1. an EXACT limb-level model of vsp_mm28 / vsp_mm28x2 (the column schedule of tools/gen_mont_asm.py body28) and of madd28 /
-    madd28_g2 (fp28.h), which asserts at every step that no column accumulator reaches 2^64, no 32-bit limb wraps in either
+    madd28_g2 / the full addition over XYZZ<Fp28> that the G1 merges and bucket reduction run (fp28.h), which asserts at every step that no column accumulator reaches 2^64, no 32-bit limb wraps in either
     direction, every product input is below 2^388 -- driven over random accumulations AND over adversarial accumulator states
     placed at the stated worst case (X just below 9.5 p with loose-as-allowed limbs, Y limbs just below 2^30, ...), and which
     compares every result with the group law computed in plain big integers;
@@ -198,6 +198,28 @@ def madd28(acc, q, negate):
     return (X3, Y3, mm28(ZZ, PP), mm28(ZZZ, PPP)), True
 
 
+def add28(a, b):
+    """fp28.h xyzz_add(XYZZ<Fp28>&, const XYZZ<Fp28>&): (sum, True), or (a, False) where the kernel takes the generic formulas (equal x)."""
+    if b is None:
+        return a, True
+    if a is None:
+        return b, True
+    X1, Y1, ZZ1, ZZZ1 = a
+    X2, Y2, ZZ2, ZZZ2 = b
+    U1, U2 = mm28(X1, ZZ2), mm28(X2, ZZ1)
+    S1, S2 = mm28(Y1, ZZZ2), mm28(Y2, ZZZ1)
+    Pd = norm28(sub28(U2, K["FP28_K8_L1"], U1))
+    PP = sq28(Pd)
+    if is_zero_product(PP, 2):
+        return a, False
+    R = norm28(sub28(S2, K["FP28_K8_L1"], S1))
+    PPP, Q = mm28(Pd, PP), mm28(U1, PP)
+    s = lin(PPP, 1, Q, 2)
+    X3 = norm28(sub28(sq28(R), K["FP28_K8_L4"], s))
+    Y3 = mm28(R, sub28(Q, K["FP28_K32_L1"], X3), neg28(K["FP28_K8_L1"], S1), PPP)
+    return (X3, Y3, mm28(mm28(ZZ1, ZZ2), PP), mm28(mm28(ZZZ1, ZZZ2), PPP)), True
+
+
 # G2: a value is a pair of component limb vectors (c0, c1) = the even and odd lane of a pair
 def mulF2(a, b, KB):
     a0, a1 = a; b0, b1 = b
@@ -330,6 +352,52 @@ def test_exact_model_adversarial_states_g1():
             madd28(acc, (tight(x), tight(y)), True)          # not a curve point: only the bound assertions matter here
 
 
+def test_exact_model_full_addition_g1():
+    """the bucket sums of the G1 path are merged and reduced in the 28-bit form (XYZZ<Fp28>): random partial sums, states at the
+    invariants' worst case on BOTH sides, and the equal-x cases (doubling, cancellation) that the kernel hands to the generic formulas"""
+    rng = random.Random(5)
+    pts = rand_points_g1(rng, 24)
+
+    def accumulate(group):
+        acc, ref = None, None
+        for pt in group:
+            acc, ok = madd28(acc, (to28(pt[0]), to28(pt[1])), False); assert ok
+            ref = o.G1.add(ref, pt)
+        return acc, ref
+
+    sums = [accumulate(pts[i:i + 3]) for i in range(0, 24, 3)]
+    while len(sums) > 1:                                   # a merge tree, as k_merge* / k_dimsum / k_dimweight fold
+        nxt = []
+        for (a, ra), (b, rb) in zip(sums[::2], sums[1::2]):
+            c, ok = add28(a, b); assert ok
+            assert acc_affine(c) == o.G1.add(ra, rb)
+            assert val(c[0]) < 9.5 * P and val(c[1]) < 8 * P and val(c[2]) < 1.1 * P and val(c[3]) < 1.1 * P
+            assert all(x <= MASK for comp in c for x in comp[:-1])
+            nxt.append((c, o.G1.add(ra, rb)))
+        sums = nxt
+    total, ref = sums[0]
+    assert acc_affine(total) == ref
+    assert add28(None, total) == (total, True) and add28(total, None) == (total, True)
+    assert add28(total, total) == (total, False)                                           # doubling
+    neg = (total[0], norm28(neg28(K["FP28_K32_L1"], total[1])), total[2], total[3])
+    assert add28(total, neg) == (total, False)                                             # cancellation
+
+    def lift(x, cap_mult):
+        kmax = int(cap_mult * 1000) * P // 1000
+        return x + ((kmax - x) // P) * P
+
+    def worst_state(pt):
+        z = rng.randrange(1, P)
+        zz, zzz = z * z % P, z * z * z % P
+        return (tight(lift(pt[0] * zz % P * RP % P, 9.5)), tight(lift(pt[1] * zzz % P * RP % P, 8.0)),
+                tight(lift(zz * RP % P, 1.1)), tight(lift(zzz * RP % P, 1.1)))
+
+    for a, b in zip(pts[:8], pts[8:16]):
+        c, ok = add28(worst_state(a), worst_state(b))
+        assert ok and acc_affine(c) == o.G1.add(a, b)
+        assert val(c[0]) < 9.5 * P and val(c[1]) < 1.5 * P
+
+
 def test_exact_model_random_and_adversarial_g2():
     rng = random.Random(3)
     F = o.Fp2Ops
@@ -442,6 +510,25 @@ def test_invariants_are_inductive_g1():
         assert X3.v <= X.v and Y3.v <= Y.v                                # inductive
     # the first addition copies the table entry: Y = 8p - y normalised, X = x, ZZ = ZZZ = one: all inside the invariants
     assert b_norm(qy_neg).v <= Y.v and qx.v <= X.v
+
+
+def test_invariants_are_inductive_full_addition_g1():
+    """the same invariants on both operands  ==>  the same after xyzz_add over XYZZ<Fp28>"""
+    X, Y, ZZ, ZZZ = B.tight(9.5 * P), B.tight(8 * P + 1), B.tight(1.1 * P), B.tight(1.1 * P)
+    U1, U2, S1, S2 = b_mul(X, ZZ), b_mul(X, ZZ), b_mul(Y, ZZZ), b_mul(Y, ZZZ)
+    assert U1.v < 1.01 * P and S1.v < 1.01 * P
+    Pd = b_norm(b_sub(U2, "FP28_K8_L1", U1)); assert Pd.v < 9.02 * P
+    PP = b_mul(Pd, Pd); assert PP.v < 1.04 * P                             # zero test against {0, p} exhaustive
+    R = b_norm(b_sub(S2, "FP28_K8_L1", S1)); assert R.v < 9.02 * P
+    PPP, Q = b_mul(Pd, PP), b_mul(U1, PP)
+    s = b_lin(PPP, 1, Q, 2); assert max(s.l[:-1]) <= 3 * (1 << W)
+    X3 = b_norm(b_sub(b_mul(R, R), "FP28_K8_L4", s)); assert X3.v < 9.1 * P
+    D = b_sub(Q, "FP28_K32_L1", X3); assert max(D.l[:-1]) <= 1 << 30
+    nS1 = b_sub(B(1, [1] * N), "FP28_K8_L1", S1); assert max(nS1.l[:-1]) <= 1 << 29
+    Y3 = b_mul(R, D, nS1, PPP); assert Y3.v < 1.13 * P
+    ZZ3, ZZZ3 = b_mul(b_mul(ZZ, ZZ), PP), b_mul(b_mul(ZZZ, ZZZ), PPP)
+    assert ZZ3.v < 1.01 * P and ZZZ3.v < 1.01 * P
+    assert X3.v <= X.v and Y3.v <= Y.v and ZZ3.v <= ZZ.v and ZZZ3.v <= ZZZ.v
 
 
 def test_invariants_are_inductive_g2():

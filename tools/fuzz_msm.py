@@ -53,6 +53,7 @@ while time.time() - t0 < budget:
     pre = bool(rng.random() < 0.5)
     ctx.set_option("msm_window_bits", wb)
     ctx.set_option("msm_split", int(rng.choice([0, 0, 0, 16, 64])))
+    glv = int(rng.choice([1, 1, 0, 2])); ctx.set_option("msm_glv", glv)      # endomorphism split: policy / off / forced
     exp = (cref.msm_g1 if group == 1 else cref.msm_g2)(bases, ss, mixed=True)
     B = ctx.upload_bases(bases, group)
     try:
@@ -68,7 +69,7 @@ while time.time() - t0 < budget:
         ctx.dfree(d_s)
     finally:
         B.free()
-    key = (group, pre, kind); stats[key] = stats.get(key, 0) + 1
+    key = (group, pre, kind, glv); stats[key] = stats.get(key, 0) + 1
     if not ok:
-        print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, kind=kind, wb=wb, pre=pre, first=first, dup=dup < 0.15)); sys.exit(1)
+        print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, kind=kind, wb=wb, pre=pre, glv=glv, first=first, dup=dup < 0.15)); sys.exit(1)
 print("fuzz ok: %d configurations in %.0f s" % (it, time.time() - t0), {str(k): c for k, c in sorted(stats.items())})

@@ -59,6 +59,7 @@ struct MsmWork {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres, medium, redo;
+    DevBuf buckets28, partials28;          // G1: bucket sums in the 14 x 28-bit form (fp28.h XYZZ<Fp28>)
     DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
     bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
     void *h_pinned = nullptr;

@@ -17,14 +17,18 @@
 // Derivation (p / 2^392 = 1 / 2521):  P = U2 + 32p - X < 33.1p,  PP = P^2 < (33.1^2 / 2521 + 1) p = 1.44p,  PPP, Q < 1.02p,
 //   R = S2 + 32p - Y < 33.5p,  R^2 < 1.45p,  s = PPP + 2Q < 3.1p (limbs < 3 * 2^28),  X3 = R^2 + 8p - s < 9.5p,
 //   Q - X3 + 32p < 33.1p (limbs < 2^30),  32p - Y1 < 32p (limbs < 2^29),  Y3 = [R (Q - X3) + (32p - Y1) PPP] / 2^392 + p < 1.5p.
-// Everything outside the accumulation kernel keeps the 12 x 32-bit form; conversion happens once per table entry (at
-// precomputation) and once per bucket part (at the store).
+// G1: the bucket sums stay in this form through the merges and the bucket reduction (XYZZ<Fp28> below); conversion happens once per
+// table entry (at precomputation) and once per window result.  G2 converts at the store of each bucket part.
 #pragma once
 #include "curve.h"
 
 namespace vsp {
 
-struct Fp28 { uint32_t l[14]; };                       // 56 bytes (no over-alignment: that would pad it to 64)
+struct Fp28 {                                          // 56 bytes (no over-alignment: that would pad it to 64)
+    uint32_t l[14];
+    VSP_HD static Fp28 zero() { Fp28 r; for (int i = 0; i < 14; i++) r.l[i] = 0; return r; }      // XYZZ<Fp28>::inf()
+};
+VSP_HD bool is_zero(const Fp28 &a) { uint32_t o = 0; for (int i = 0; i < 14; i++) o |= a.l[i]; return o == 0; }
 // Table rows are padded to whole 128-byte cache lines: a gathered G1 point is ONE line (112 bytes of payload), a G2 point two.
 // Unpadded 112 / 224-byte rows straddled two / three lines in 6 of 8 alignments: 273 bytes fetched per 112-byte gather (round 1 PMC).
 struct alignas(128) Affine28 { Fp28 x, y; };
@@ -178,6 +182,55 @@ __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool nega
     acc.ZZZ = mul28(acc.ZZZ, PPP);
     return true;
 }
+// ---- the bucket sums of the G1 path stay in the 28-bit form through the merges and the bucket reduction: XYZZ<Fp28>, 224 bytes, the
+// layout of XYZZ28.  acc += q, both XYZZ (add-2008-s), under the invariants of the header -- which the result satisfies again:
+//   U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1            product outputs: tight, < 1.01p  (X < 9.5p, Y < 8p, ZZ, ZZZ < 1.1p)
+//   P = U2 + 8p - U1, R = S2 + 8p - S1                               tight after the carry pass, < 9.01p
+//   PP = P^2 < 1.04p, PPP = P PP, Q = U1 PP < 1.01p,  X3 = R^2 + 8p - (PPP + 2Q) < 9.1p
+//   Y3 = [R (Q + 32p - X3) + (8p - S1) PPP] / 2^392 + p < 1.13p      limb bounds 28+30 and 29+28 as in madd28
+//   ZZ3 = (ZZ1 ZZ2) PP, ZZZ3 = (ZZZ1 ZZZ2) PPP < 1.01p
+// 12 products + 2 squares.  Equal x (P = 0: a doubling or a cancellation -- coinciding partial sums, e.g. duplicated bases) takes the
+// generic 12 x 32-bit formulas through a conversion: rare, and always right.  tests/test_fp28_bounds.py models this function too.
+__device__ __forceinline__ XYZZ<Fp28> xyzz28_from_fp(const XYZZ<Fp> &a) {
+    XYZZ<Fp28> r;
+    if (is_inf(a)) return XYZZ<Fp28>::inf();
+    r.X = fp_to_fp28(a.X); r.Y = fp_to_fp28(a.Y); r.ZZ = fp_to_fp28(a.ZZ); r.ZZZ = fp_to_fp28(a.ZZZ);
+    return r;
+}
+__device__ __forceinline__ XYZZ<Fp> xyzz28_to_fp(const XYZZ<Fp28> &a) {
+    XYZZ<Fp> r;
+    if (fp28_all_zero(a.ZZ)) return XYZZ<Fp>::inf();
+    r.X = fp28_to_fp(a.X); r.Y = fp28_to_fp(a.Y); r.ZZ = fp28_to_fp(a.ZZ); r.ZZZ = fp28_to_fp(a.ZZZ);
+    return r;
+}
+// (a real call on memory operands: inlined, the generic formulas crash this toolchain's scheduler next to the product routines; the
+// caller copies its registers into temporaries inside the cold branch, so the hot path keeps everything in registers)
+__device__ __noinline__ void xyzz_add28_equal_x(XYZZ<Fp28> *acc, const XYZZ<Fp28> *q) {
+    XYZZ<Fp> a = xyzz28_to_fp(*acc), b = xyzz28_to_fp(*q);
+    xyzz_add(a, b);
+    *acc = xyzz28_from_fp(a);
+}
+__device__ __forceinline__ void xyzz_add(XYZZ<Fp28> &acc, const XYZZ<Fp28> &q) {
+    if (fp28_all_zero(q.ZZ)) return;
+    if (fp28_all_zero(acc.ZZ)) { acc = q; return; }
+    Fp28 U1 = mul28(acc.X, q.ZZ), U2 = mul28(q.X, acc.ZZ);
+    Fp28 S1 = mul28(acc.Y, q.ZZZ), S2 = mul28(q.Y, acc.ZZZ);
+    Fp28 P = norm28(sub28(U2, FP28_K8_L1, U1));
+    Fp28 PP = sqr28(P);
+    if (fp28_product_is_zero(PP)) { XYZZ<Fp28> ta = acc, tq = q; xyzz_add28_equal_x(&ta, &tq); acc = ta; return; }
+    Fp28 R = norm28(sub28(S2, FP28_K8_L1, S1));
+    Fp28 PPP = mul28(P, PP);
+    Fp28 Q = mul28(U1, PP);
+    Fp28 s;
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
+    Fp28 X3 = norm28(sub28(sqr28(R), FP28_K8_L4, s));
+    acc.Y = mul28x2(R, sub28(Q, FP28_K32_L1, X3), neg28(FP28_K8_L1, S1), PPP);
+    acc.X = X3;
+    acc.ZZ = mul28(mul28(acc.ZZ, q.ZZ), PP);
+    acc.ZZZ = mul28(mul28(acc.ZZZ, q.ZZZ), PPP);
+}
+
 // ================================================================ G2: Fp2 over the 28-bit form, one Fp2 value per lane pair
 // (even lane c0, odd lane c1, as Fp2L in field.h).  A product is ONE dual product per lane (schoolbook, one reduction):
 //   even lane  a0 b0 + a1 (K - b1),   odd lane  a0 b1 + a1 b0;     a square is one single product per lane:
@@ -262,6 +315,9 @@ __device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q
     acc.ZZZ = mulF2(acc.ZZZ, PPP, FP28_K8_L1);
     return true;
 }
+#else
+// host pass: kernels instantiated over XYZZ<Fp28> are only type-checked here (the product routines exist in the device pass alone)
+__device__ __forceinline__ void xyzz_add(XYZZ<Fp28> &, const XYZZ<Fp28> &) {}
 #endif
 
 }  // namespace vsp

@@ -241,16 +241,23 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
     if (overlap && *overlap) (*overlap)();
     lap("prove_host_overlap_ms");
-    VSP_TRY(msm_g1_finish(ctx, 1, &eA)); VSP_TRY(msm_g1_finish(ctx, 2, &eB1)); VSP_TRY(msm_g1_finish(ctx, 4, &eL));
-    VSP_TRY(msm_g1_finish(ctx, 0, &eH)); VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
+    // The witness multi-exponentiations finish long before the H chain (witness_map, then the dense H query): the two 255-bit scalar
+    // multiplications of the assembly, s * A and r * B1 (0.3 ms of host time), are done as soon as their operands exist, inside the wait
+    VSP_TRY(msm_g1_finish(ctx, 1, &eA));
+    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
+    XYZZ<HFp> s_gA = xyzz_mul_scalar(gA, s, 255);
+    VSP_TRY(msm_g1_finish(ctx, 2, &eB1));
+    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
+    XYZZ<HFp> r_gB1 = xyzz_mul_scalar(gB1, r, 255);
+    VSP_TRY(msm_g1_finish(ctx, 4, &eL));
+    VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
+    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2);
+    VSP_TRY(msm_g1_finish(ctx, 0, &eH));
     lap("prove_wait_ms");
     // assembly: a handful of group operations
-    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
-    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
-    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2);
     XYZZ<HFp> gC = eH; xyzz_add(gC, eL);
-    { XYZZ<HFp> t = xyzz_mul_scalar(gA, s, 255); xyzz_add(gC, t); }
-    { XYZZ<HFp> t = xyzz_mul_scalar(gB1, r, 255); xyzz_add(gC, t); }
+    xyzz_add(gC, s_gA);
+    xyzz_add(gC, r_gB1);
     xyzz_add(gC, neg_rs_delta);
     xyzz_add(gC, saver);
     Affine<HFp> a = xyzz_to_affine(gA), c = xyzz_to_affine(gC);
