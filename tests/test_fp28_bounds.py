@@ -264,6 +264,31 @@ def madd28_g2(acc, q, negate):
     return (X3, Y3, mulF2(ZZ, PP, K8), mulF2(ZZZ, PPP, K8)), True
 
 
+def add28_g2(a, b):
+    """fp28.h xyzz_add(XYZZ<Fp28L>&, const XYZZ<Fp28L>&): the full addition over Fp2 on lane pairs; (sum, True) or (a, False) at equal x"""
+    if b is None:
+        return a, True
+    if a is None:
+        return b, True
+    X1, Y1, ZZ1, ZZZ1 = a
+    X2, Y2, ZZ2, ZZZ2 = b
+    K8, K32, K64L4, K8L4 = (K[n] for n in ("FP28_K8_L1", "FP28_K32_L1", "FP28_K64_L4", "FP28_K8_L4"))
+    U1, U2 = mulF2(X1, ZZ2, K8), mulF2(X2, ZZ1, K8)
+    S1, S2 = mulF2(Y1, ZZZ2, K8), mulF2(Y2, ZZZ1, K8)
+    Pd = tuple(norm28(sub28(u2, K8, u1)) for u2, u1 in zip(U2, U1))
+    PP = sqrF2(Pd, K32)
+    if all(is_zero_product(c, 2) for c in PP):
+        return a, False
+    R = tuple(norm28(sub28(s2, K8, s1)) for s2, s1 in zip(S2, S1))
+    PPP, Q = mulF2(Pd, PP, K8), mulF2(U1, PP, K8)
+    s = tuple(lin(x, 1, y, 2) for x, y in zip(PPP, Q))
+    X3 = tuple(norm28(sub28(rr, K8L4, ss)) for rr, ss in zip(sqrF2(R, K32), s))
+    D = tuple(sub28(qq, K32, x3) for qq, x3 in zip(Q, X3))
+    t1, t2 = mulF2(R, D, K64L4), mulF2(S1, PPP, K8)
+    Y3 = tuple(sub28(x, K8, y) for x, y in zip(t1, t2))
+    return (X3, Y3, mulF2(mulF2(ZZ1, ZZ2, K8), PP, K8), mulF2(mulF2(ZZZ1, ZZZ2, K8), PPP, K8)), True
+
+
 # ------------------------------------------------------------------------------------------------ reference values in plain integers
 RINV = pow(RP, -1, P)
 
@@ -436,6 +461,54 @@ def test_exact_model_random_and_adversarial_g2():
             assert ok and acc_affine_g2(new) == o.G2.add(base, o.G2.neg(pt) if negate else pt)
 
 
+def test_exact_model_full_addition_g2():
+    """the G2 bucket sums are merged and reduced in the lane-pair 28-bit form too: a merge tree over random partial sums, the equal-x
+    cases, and operands lifted to the invariants' worst case (X < 11.7 p, Y < 10.4 p with limbs up to 2^30, ZZ, ZZZ < 3.9 p)"""
+    rng = random.Random(6)
+    F = o.Fp2Ops
+    pts = [o.G2.mul(o.G2.gen, rng.randrange(1, o.R)) for _ in range(16)]
+    to2 = lambda pt: ((to28(pt[0][0]), to28(pt[0][1])), (to28(pt[1][0]), to28(pt[1][1])))
+
+    def accumulate(group):
+        acc, ref = None, None
+        for pt in group:
+            acc, ok = madd28_g2(acc, to2(pt), False); assert ok
+            ref = o.G2.add(ref, pt)
+        return acc, ref
+
+    sums = [accumulate(pts[i:i + 2]) for i in range(0, 16, 2)]
+    while len(sums) > 1:
+        nxt = []
+        for (a, ra), (b, rb) in zip(sums[::2], sums[1::2]):
+            c, ok = add28_g2(a, b); assert ok
+            assert acc_affine_g2(c) == o.G2.add(ra, rb)
+            for comp in range(2):
+                assert val(c[0][comp]) < 11.7 * P and val(c[1][comp]) < 10.4 * P and val(c[2][comp]) < 3.9 * P and val(c[3][comp]) < 3.9 * P
+                assert all(x <= MASK for k in (0, 2, 3) for x in c[k][comp][:-1]) and all(x < 1 << 30 for x in c[1][comp][:-1])
+            nxt.append((c, o.G2.add(ra, rb)))
+        sums = nxt
+    total, ref = sums[0]
+    assert add28_g2(total, total) == (total, False)
+    neg = (total[0], tuple(norm28(neg28(K["FP28_K32_L4"], c)) for c in total[1]), total[2], total[3])
+    assert add28_g2(total, neg) == (total, False)
+
+    def lift(x, cap_mult):
+        kmax = int(cap_mult * 1000) * P // 1000
+        return x + ((kmax - x) // P) * P
+
+    def worst_state(pt):
+        z = (rng.randrange(1, P), rng.randrange(1, P))
+        zz = F.mul(z, z); zzz = F.mul(zz, z)
+        X, Y = F.mul(pt[0], zz), F.mul(pt[1], zzz)
+        mont = lambda v, cap: tuple(tight(lift(c * RP % P, cap)) for c in v)
+        Yl = tuple(loosen(lift(c * RP % P, 10.4), 1 << 30, rng) for c in Y)
+        return (mont(X, 11.7), Yl, mont(zz, 3.9), mont(zzz, 3.9))
+
+    for a, b in zip(pts[:6], pts[6:12]):
+        c, ok = add28_g2(worst_state(a), worst_state(b))
+        assert ok and acc_affine_g2(c) == o.G2.add(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ worst-case propagation
 class B:
     """upper bounds of a quantity: value < v, limb i < l[i] (exclusive)"""
@@ -563,6 +636,36 @@ def test_invariants_are_inductive_g2():
         ZZ3, ZZZ3 = pair_mul(ZZ, PP, "FP28_K8_L1"), pair_mul(ZZZ, PPP, "FP28_K8_L1")
         assert ZZ3.v < 3.9 * P and ZZZ3.v < 3.9 * P
         assert X3.v <= X.v and Y3.v <= Y.v
+
+
+def test_invariants_are_inductive_full_addition_g2():
+    """the lane-pair invariants on both operands  ==>  the same after xyzz_add over XYZZ<Fp28L>"""
+    def pair_mul(a, b, kb):
+        nb = b_sub(B(1, [1] * N), kb, b)
+        e, od = b_mul(a, b, a, nb), b_mul(a, b, a, b)
+        return e if e.v > od.v else od
+
+    def pair_sqr(a, ka):
+        e, od = b_mul(b_lin(a, 1, a, 1), b_sub(a, ka, a)), b_mul(a, b_lin(a, 2, B(1, [1] * N), 0))
+        return e if e.v > od.v else od
+
+    X, ZZ, ZZZ = B.tight(11.7 * P), B.tight(3.9 * P), B.tight(3.9 * P)
+    Y = B(int(10.4 * P), [1 << 30] * (N - 1) + [(int(10.4 * P) >> (W * (N - 1))) + 1])
+    U1, S1 = pair_mul(X, ZZ, "FP28_K8_L1"), pair_mul(Y, ZZZ, "FP28_K8_L1")
+    assert U1.v < 1.06 * P and S1.v < 1.06 * P
+    Pd = b_norm(b_sub(U1, "FP28_K8_L1", U1)); assert Pd.v < 9.1 * P
+    PP = pair_sqr(Pd, "FP28_K32_L1"); assert PP.v < 1.31 * P                # zero test against {0, p} exhaustive (< 2p)
+    R = b_norm(b_sub(S1, "FP28_K8_L1", S1)); assert R.v < 9.1 * P
+    PPP, Q = pair_mul(Pd, PP, "FP28_K8_L1"), pair_mul(U1, PP, "FP28_K8_L1")
+    s = b_lin(PPP, 1, Q, 2)
+    X3 = b_norm(b_sub(pair_sqr(R, "FP28_K32_L1"), "FP28_K8_L4", s)); assert X3.v < 9.4 * P
+    D = b_sub(Q, "FP28_K32_L1", X3); assert max(D.l[:-1]) <= 1 << 30
+    t1, t2 = pair_mul(R, D, "FP28_K64_L4"), pair_mul(S1, PPP, "FP28_K8_L1")
+    Y3 = b_sub(t1, "FP28_K8_L1", t2); assert Y3.v < 9.5 * P and max(Y3.l[:-1]) <= 1 << 30
+    ZZ3 = pair_mul(pair_mul(ZZ, ZZ, "FP28_K8_L1"), PP, "FP28_K8_L1")
+    ZZZ3 = pair_mul(pair_mul(ZZZ, ZZZ, "FP28_K8_L1"), PPP, "FP28_K8_L1")
+    assert ZZ3.v < 1.02 * P and ZZZ3.v < 1.02 * P
+    assert X3.v <= X.v and Y3.v <= Y.v and ZZ3.v <= ZZ.v and ZZZ3.v <= ZZZ.v
 
 
 def test_the_model_notices_a_broken_bound():

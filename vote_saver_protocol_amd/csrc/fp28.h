@@ -34,6 +34,11 @@ VSP_HD bool is_zero(const Fp28 &a) { uint32_t o = 0; for (int i = 0; i < 14; i++
 struct alignas(128) Affine28 { Fp28 x, y; };
 static_assert(sizeof(Fp28) == 56 && sizeof(Affine28) == 128, "G1 table rows are one 128-byte line");
 struct XYZZ28 { Fp28 X, Y, ZZ, ZZZ; };
+// G2 bucket sums in the 28-bit form: memory holds Fp2x28 values (c0, c1: 112 bytes; XYZZ<Fp2x28> = 448 bytes), a lane of a pair holds
+// one component (Fp28L), exactly as Fp2 / Fp2L in field.h
+struct Fp2x28 { Fp28 c0, c1; VSP_HD static Fp2x28 zero() { Fp2x28 r; r.c0 = Fp28::zero(); r.c1 = Fp28::zero(); return r; } };
+struct Fp28L { Fp28 v; VSP_HD static Fp28L zero() { Fp28L r; r.v = Fp28::zero(); return r; } };
+VSP_HD bool is_zero(const Fp2x28 &a) { return is_zero(a.c0) && is_zero(a.c1); }
 struct alignas(256) Affine28x2 { Fp28 xc0, xc1, yc0, yc1; };     // one G2 point of the 28-bit table: 224 bytes of payload in two lines
 static_assert(sizeof(Affine28x2) == 256, "G2 table rows are two 128-byte lines");
 
@@ -315,9 +320,55 @@ __device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q
     acc.ZZZ = mulF2(acc.ZZZ, PPP, FP28_K8_L1);
     return true;
 }
+
+// acc += q, both XYZZ over Fp2 on lane pairs (add-2008-s), for the G2 merges and bucket reduction.  Invariants as madd28_g2 keeps them
+// (X tight < 11.7p, Y limbs < 2^30 and < 10.4p, ZZ, ZZZ tight < 3.9p), and the result satisfies them again:
+//   U1 = X1 ZZ2, U2 = X2 ZZ1 (28+28, 28+29) < 1.06p;  S1 = Y1 ZZZ2, S2 = Y2 ZZZ1 (30+28, 30+29) < 1.05p
+//   P = U2 + 8p - U1, R = S2 + 8p - S1: tight after the carry pass, < 9.1p;  PP, RR = squares with K = 32p: (29, 29.6), < 1.3p
+//   PPP = P PP, Q = U1 PP < 1.04p;  X3 = RR + 8p - (PPP + 2Q) < 9.3p;  D = Q + 32p - X3 (limbs < 2^30)
+//   Y3 = R D + 8p - S1 PPP: t1 < 1.36p (28+30, 28+30.3), limbs of Y3 < 2^30, value < 9.4p;  ZZ3, ZZZ3 = two products each, < 1.01p
+// Equal x goes through the generic lane-pair formulas (a real call, see xyzz_add28_equal_x).
+__device__ __forceinline__ bool is_zero(const Fp28L &a) { return pair_all28(fp28_all_zero(a.v)); }
+__device__ __noinline__ void xyzz_add28_equal_x_g2(XYZZ<Fp28L> *acc, const XYZZ<Fp28L> *q) {
+    auto to_generic = [](const XYZZ<Fp28L> &a) {
+        XYZZ<Fp2L> r = XYZZ<Fp2L>::inf();
+        if (!pair_all28(fp28_all_zero(a.ZZ.v))) { r.X.v = fp28_to_fp(a.X.v); r.Y.v = fp28_to_fp(a.Y.v); r.ZZ.v = fp28_to_fp(a.ZZ.v); r.ZZZ.v = fp28_to_fp(a.ZZZ.v); }
+        return r;
+    };
+    XYZZ<Fp2L> a = to_generic(*acc), b = to_generic(*q);
+    xyzz_add(a, b);
+    XYZZ<Fp28L> r = XYZZ<Fp28L>::inf();
+    if (!is_inf(a)) { r.X.v = fp_to_fp28(a.X.v); r.Y.v = fp_to_fp28(a.Y.v); r.ZZ.v = fp_to_fp28(a.ZZ.v); r.ZZZ.v = fp_to_fp28(a.ZZZ.v); }
+    *acc = r;
+}
+__device__ __forceinline__ void xyzz_add(XYZZ<Fp28L> &acc, const XYZZ<Fp28L> &q) {
+    if (pair_all28(fp28_all_zero(q.ZZ.v))) return;
+    if (pair_all28(fp28_all_zero(acc.ZZ.v))) { acc = q; return; }
+    Fp28 U1 = mulF2(acc.X.v, q.ZZ.v, FP28_K8_L1), U2 = mulF2(q.X.v, acc.ZZ.v, FP28_K8_L1);
+    Fp28 S1 = mulF2(acc.Y.v, q.ZZZ.v, FP28_K8_L1), S2 = mulF2(q.Y.v, acc.ZZZ.v, FP28_K8_L1);
+    Fp28 P = norm28(sub28(U2, FP28_K8_L1, U1));
+    Fp28 PP = sqrF2(P, FP28_K32_L1);
+    if (pair_all28(fp28_product_is_zero(PP))) { XYZZ<Fp28L> ta = acc, tq = q; xyzz_add28_equal_x_g2(&ta, &tq); acc = ta; return; }
+    Fp28 R = norm28(sub28(S2, FP28_K8_L1, S1));
+    Fp28 PPP = mulF2(P, PP, FP28_K8_L1);
+    Fp28 Q = mulF2(U1, PP, FP28_K8_L1);
+    Fp28 s;
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
+    Fp28 X3 = norm28(sub28(sqrF2(R, FP28_K32_L1), FP28_K8_L4, s));
+    Fp28 D = sub28(Q, FP28_K32_L1, X3);
+    Fp28 t1 = mulF2(R, D, FP28_K64_L4);
+    Fp28 t2 = mulF2(S1, PPP, FP28_K8_L1);
+    acc.Y.v = sub28(t1, FP28_K8_L1, t2);
+    acc.X.v = X3;
+    acc.ZZ.v = mulF2(mulF2(acc.ZZ.v, q.ZZ.v, FP28_K8_L1), PP, FP28_K8_L1);
+    acc.ZZZ.v = mulF2(mulF2(acc.ZZZ.v, q.ZZZ.v, FP28_K8_L1), PPP, FP28_K8_L1);
+}
 #else
-// host pass: kernels instantiated over XYZZ<Fp28> are only type-checked here (the product routines exist in the device pass alone)
+// host pass: kernels instantiated over XYZZ<Fp28> / XYZZ<Fp28L> are only type-checked here (the product routines exist in the device
+// pass alone)
 __device__ __forceinline__ void xyzz_add(XYZZ<Fp28> &, const XYZZ<Fp28> &) {}
+__device__ __forceinline__ void xyzz_add(XYZZ<Fp28L> &, const XYZZ<Fp28L> &) {}
 #endif
 
 }  // namespace vsp

@@ -1,6 +1,7 @@
 // Lane view of the group arithmetic, shared by the MSM and fixed-base kernels.
 #pragma once
 #include "curve.h"
+#include "fp28.h"
 
 namespace vsp {
 
@@ -31,6 +32,20 @@ template <> struct LaneView<Fp2> {
     }
     __device__ __forceinline__ static void store(XYZZ<Fp2> *p, const XYZZ<E> &v) {
         Fp *row = reinterpret_cast<Fp *>(p);
+        row[comp()] = v.X.v; row[2 + comp()] = v.Y.v; row[4 + comp()] = v.ZZ.v; row[6 + comp()] = v.ZZZ.v;
+    }
+};
+// the 28-bit form of the same split (fp28.h): memory XYZZ<Fp2x28> = X.c0, X.c1, Y.c0, ... (56 bytes each), a lane holds XYZZ<Fp28L>
+template <> struct LaneView<Fp2x28> {
+    using E = Fp28L;
+    static constexpr unsigned LANES = 2;
+    __device__ __forceinline__ static unsigned comp() { return threadIdx.x & 1; }
+    __device__ __forceinline__ static XYZZ<E> load(const XYZZ<Fp2x28> *p) {
+        const Fp28 *row = reinterpret_cast<const Fp28 *>(p);
+        XYZZ<E> r; r.X.v = row[comp()]; r.Y.v = row[2 + comp()]; r.ZZ.v = row[4 + comp()]; r.ZZZ.v = row[6 + comp()]; return r;
+    }
+    __device__ __forceinline__ static void store(XYZZ<Fp2x28> *p, const XYZZ<E> &v) {
+        Fp28 *row = reinterpret_cast<Fp28 *>(p);
         row[comp()] = v.X.v; row[2 + comp()] = v.Y.v; row[4 + comp()] = v.ZZ.v; row[6 + comp()] = v.ZZZ.v;
     }
 };
