@@ -125,7 +125,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     import threading
     n_ctx = int(os.environ.get("VSP_BENCH_PROVE_CONTEXTS", "2"))
     extra_ctx = [v.Context(ctx.device) for _ in range(n_ctx - 1)]
-    per_thread = 6
+    per_thread = 20                                        # (7 proofs per thread gave figures that jumped 30 % between runs)
     outs = {}
 
     def worker(c, tag):

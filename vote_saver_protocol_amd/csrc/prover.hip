@@ -243,17 +243,20 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     lap("prove_host_overlap_ms");
     // The witness multi-exponentiations finish long before the H chain (witness_map, then the dense H query): the two 255-bit scalar
     // multiplications of the assembly, s * A and r * B1 (0.3 ms of host time), are done as soon as their operands exist, inside the wait
+    long early = 1; { auto it = ctx->opts.find("prove_early_assembly"); if (it != ctx->opts.end()) early = it->second; }
+    XYZZ<HFp> gA, gB1, s_gA, r_gB1;
     VSP_TRY(msm_g1_finish(ctx, 1, &eA));
-    XYZZ<HFp> gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
-    XYZZ<HFp> s_gA = xyzz_mul_scalar(gA, s, 255);
+    gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
+    if (early) s_gA = xyzz_mul_scalar(gA, s, 255);
     VSP_TRY(msm_g1_finish(ctx, 2, &eB1));
-    XYZZ<HFp> gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
-    XYZZ<HFp> r_gB1 = xyzz_mul_scalar(gB1, r, 255);
+    gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
+    if (early) r_gB1 = xyzz_mul_scalar(gB1, r, 255);
     VSP_TRY(msm_g1_finish(ctx, 4, &eL));
     VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
     XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2);
     VSP_TRY(msm_g1_finish(ctx, 0, &eH));
     lap("prove_wait_ms");
+    if (!early) { s_gA = xyzz_mul_scalar(gA, s, 255); r_gB1 = xyzz_mul_scalar(gB1, r, 255); }
     // assembly: a handful of group operations
     XYZZ<HFp> gC = eH; xyzz_add(gC, eL);
     xyzz_add(gC, s_gA);
