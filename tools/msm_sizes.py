@@ -5,7 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import vote_saver_protocol_amd as v  # noqa: E402
 rng = np.random.default_rng(1)
-for group, lgs in ((1, (16, 18, 19, 20)), (2, (16, 18, 19))):
+plan = ((1, (16, 18, 19, 20)), (2, (16, 18, 19)))
+if os.environ.get("SIZES"):                                   # e.g. SIZES="1:21,22;2:19,20"
+    plan = tuple((int(p.split(":")[0]), tuple(int(x) for x in p.split(":")[1].split(","))) for p in os.environ["SIZES"].split(";"))
+for group, lgs in plan:
     for lg in lgs:
         n = 1 << lg
         ks = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); ks[:, 3] >>= np.uint64(2)

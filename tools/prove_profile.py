@@ -9,6 +9,8 @@ import vote_saver_protocol_amd as v
 lg = int(os.environ.get("LOG_M", "20")); reps = int(os.environ.get("REPS", "20"))
 ni = 30; nc = (1 << lg) - ni - 2
 ctx = v.Context(0)
+for kv in [x for x in os.environ.get("OPTS", "").split(",") if x]:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 gen = o.splitmix64(5)
 cs, wit = cref.R1CS.synth(nc, ni, 4, ballot=(25, 7))
 tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
