@@ -633,8 +633,8 @@ def main():
         for group, lg in ((1, args.config5_log_g1), (2, args.config5_log_g2)):
             prob = ShardedMsm(ctx, v, torch, dev, group, 1 << lg, world, rank, seed=55 + group)
             ctx.stats_reset()
-            k5 = 3
-            el5, res5 = run_sharded(prob, k5, 1, exchange, barrier, depth)
+            k5 = 2 * depth
+            el5, res5 = run_sharded(prob, k5, depth, exchange, barrier, depth)      # warm-up = one MSM per work slot: their multi-GB workspaces are allocated on first use
             el5 = allmax(el5)
             e5 = gather_e(prob.e_local)
             tag = "g1" if group == 1 else "g2"
