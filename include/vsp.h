@@ -68,7 +68,11 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
  * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
  * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
- * 12 x 32-bit kernel runs) */
+ * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
+ * "prove_early_assembly" (default 1: s*A and r*B1 are computed on the host as soon as those two results arrive, inside the wait for
+ * the H chain), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library); diagnostics:
+ * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
+ * multi-exponentiation -- a blocking read-back). */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
 
 /* ---- raw device memory helpers (for callers without torch) --------------------------------- */

@@ -16,6 +16,9 @@ cs, wit = cref.R1CS.synth(nc, ni, 4, ballot=(25, 7))
 tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
 dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
 r = np.array(o.int_to_limbs(o.rand_fr(gen), 4), np.uint64); s = np.array(o.int_to_limbs(o.rand_fr(gen), 4), np.uint64)
+if os.environ.get("ZERO_ONES"):                      # experiment: how long does a proof take without the all-ones bucket? (not a valid witness)
+    ones = (wit[:, 0] == 1) & (wit[:, 1] == 0) & (wit[:, 2] == 0) & (wit[:, 3] == 0)
+    wit[ones] = 0
 wit = ctx.host_register(np.ascontiguousarray(wit))
 kp = v.Keypair(ctx, dcs, tox, precompute=int(os.environ.get("PRE", "1")))
 v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
