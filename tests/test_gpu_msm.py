@@ -192,6 +192,39 @@ def test_msm_g2_2p18_discrete_log_identity(ctx, cref, precompute):
         B.free(); ctx.dfree(d_b); ctx.dfree(d_k); ctx.dfree(d_s)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("precompute", [False, True])
+def test_msm_equal_partial_sums_in_the_28bit_merges(ctx, cref, group, precompute):
+    """Every base is the same point P (or -P) and every scalar is one: the all-ones bucket is cut into parts whose sums are
+    IDENTICAL multiples of P, so the merges and the bucket reduction -- which run on the 28-bit form (fp28.h xyzz_add over XYZZ<Fp28> /
+    XYZZ<Fp28L>) -- meet equal x at every level: doublings with (P, P, ...), cancellations with (P, -P, ...) blocks.  Both are the
+    cold path that goes through the generic formulas."""
+    gen = (cref.g1_batch_mul_gen if group == 1 else cref.g2_batch_mul_gen)(rand_fr_array(1, seed=171))[0]
+    Pt = (o.g1_from_limbs if group == 1 else o.g2_from_limbs)(gen)
+    G = o.G1 if group == 1 else o.G2
+    neg = np.array((g1_limbs if group == 1 else g2_limbs)(G.neg(Pt)), dtype=np.uint64)
+    ref = cref.msm_g1 if group == 1 else cref.msm_g2
+    for n, pattern in ((5000, "same"), (40000, "same"), (40000, "blocks"), (4096, "alternate")):
+        bases = np.tile(gen, (n, 1))
+        if pattern == "blocks":
+            bases[(np.arange(n) // 16) % 2 == 1] = neg            # parts of 16 points: +16 P, -16 P, ... -> cancellations in the merge tree
+        elif pattern == "alternate":
+            bases[1::2] = neg
+        ss = np.zeros((n, 4), dtype=np.uint64); ss[:, 0] = 1
+        ss[::97] = rand_fr_array(len(ss[::97]), seed=172)          # a few dense scalars so that every window has buckets
+        exp = ref(bases, ss, mixed=True)
+        B = ctx.upload_bases(bases, group)
+        if precompute:
+            B.precompute(0)
+        d_s = ctx.to_device(ss)
+        try:
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, exp), (n, pattern)
+        finally:
+            ctx.dfree(d_s); B.free()
+
+
 @pytest.mark.parametrize("precompute", [False, True])
 def test_msm_duplicate_bases_take_the_equal_x_path(ctx, cref, precompute):
     """Only ten distinct points (and their negatives) among 4000 bases: buckets keep meeting equal x -- doublings and
