@@ -433,7 +433,7 @@ def main():
                       "not measurable in-process (PMC passes need rocprofv3): it is read from traffic_source"}
         rv = {"bound": "v_mad_u64_u32 issue", "kernel": rl["kernel"], "achieved": mads / (excl_ms * 1e-3) / 1e12, "peak": VALU_PEAK_MADS / 1e12,
               "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads / (excl_ms * 1e-3) / VALU_PEAK_MADS, "mads_per_mixed_addition": MADS_PER_ADD[group],
-              "mixed_additions_per_launch": n_points * (2 if split else 1) * windows, "endomorphism_split": bool(split), "peak_source": "profiles/r1_ubench_valu.txt (tools/ubench_valu.hip, measured on MI355X)"}
+              "mixed_additions_per_launch": n_points * (2 if split else 1) * windows, "endomorphism_split": bool(split), "peak_source": "profiles/r2_ubench_valu.txt (tools/ubench_valu.hip, measured on one MI355X of the pool; boxes differ by a few per cent in clock, so frac reads 0.91-1.02 for one build)"}
         return rl, rv
 
     extras = {}
