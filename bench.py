@@ -272,22 +272,30 @@ class ShardedMsm:
 
 
 def run_sharded(problem, steps, warmup, exchange, barrier, depth):
-    """`steps` MSMs over the rank's chunk + exchange, `depth` in flight; returns (seconds for `steps`, last folded result)"""
+    """`steps` MSMs over the rank's chunk + exchange, `depth` in flight; returns (seconds for `steps`, last folded result).
+    exchange = (begin, end): the exchange of step k completes while step k + 1's multi-exponentiation is awaited"""
+    x_begin, x_end = exchange
     sl = (1, 2, 4, 5)[:max(1, min(4, depth))]
     D = len(sl)
 
     def go(k_steps):
-        res = None
-        if D == 1:
-            for _ in range(k_steps):
-                res = exchange(problem.bases.msm_jacobian(problem.d_s), problem.group)
-            return res
-        for k in range(min(D - 1, k_steps)):
-            problem.bases.msm_launch(sl[k % D], problem.d_s)
+        res = None; pending = None
+        if D > 1:
+            for k in range(min(D - 1, k_steps)):
+                problem.bases.msm_launch(sl[k % D], problem.d_s)
         for k in range(k_steps):
-            if k + D - 1 < k_steps:
-                problem.bases.msm_launch(sl[(k + D - 1) % D], problem.d_s)
-            res = exchange(problem.bases.msm_finish_jacobian(sl[k % D]), problem.group)
+            if D == 1:
+                rec = problem.bases.msm_jacobian(problem.d_s)
+            else:
+                if k + D - 1 < k_steps:
+                    problem.bases.msm_launch(sl[(k + D - 1) % D], problem.d_s)
+                rec = problem.bases.msm_finish_jacobian(sl[k % D])
+            h = x_begin(rec, problem.group, k & 1)
+            if pending is not None:
+                res = x_end(pending)
+            pending = h
+        if pending is not None:
+            res = x_end(pending)
         return res
 
     if warmup:
@@ -356,15 +364,28 @@ def main():
         ctx.set_option("prove_h_first", args.prove_h_first)
     depth = 1 if args.no_pipeline else args.pipeline_depth
 
-    rec_dev = {g: torch.zeros(18 * g, dtype=torch.int64, device=dev) for g in (1, 2)}
-    all_dev = {g: torch.zeros(18 * g * world, dtype=torch.int64, device=dev) for g in (1, 2)}
+    # exchange step: one Jacobian record per rank (144 B G1 / 288 B G2), all-gathered over RCCL, folded locally.  Two buffers per group:
+    # the all-gather of step k is in flight while the host waits for the multi-exponentiation of step k + 1 (exchange_begin / _end),
+    # so its latency -- a small kernel that has to find a wave slot on a GPU full of accumulation waves, ~0.2 ms -- stays off the step time
+    rec_dev = {g: [torch.zeros(18 * g, dtype=torch.int64, device=dev) for _ in range(2)] for g in (1, 2)}
+    all_dev = {g: [torch.zeros(18 * g * world, dtype=torch.int64, device=dev) for _ in range(2)] for g in (1, 2)}
+    x_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
-    def exchange(rec, group=1):
+    def exchange_begin(rec, group=1, buf=0):
+        if not use_dist:
+            return (None, rec, group, buf)
+        with torch.cuda.stream(x_stream):
+            rec_dev[group][buf].copy_(torch.from_numpy(rec.view(np.int64)))
+            work = dist.all_gather_into_tensor(all_dev[group][buf], rec_dev[group][buf], async_op=True)
+        return (work, None, group, buf)
+
+    def exchange_end(h):
+        work, rec, group, buf = h
         w = 18 * group
-        if use_dist:                                        # exchange step: one Jacobian record per rank (144 B G1 / 288 B G2)
-            rec_dev[group].copy_(torch.from_numpy(rec.view(np.int64)))
-            dist.all_gather_into_tensor(all_dev[group], rec_dev[group])
-            recs = all_dev[group].cpu().numpy().view(np.uint64).reshape(world, w)
+        if work is not None:
+            work.wait()
+            with torch.cuda.stream(x_stream):
+                recs = all_dev[group][buf].cpu().numpy().view(np.uint64).reshape(world, w)
         else:
             recs = rec.reshape(1, w)
         return v.fold_jacobian(ctx, recs, group)            # local fold + affine normalisation
@@ -447,13 +468,13 @@ def main():
         total = 1 << lg_total
         prob = ShardedMsm(ctx, v, torch, dev, group, total, world, rank, seed=77 + group)
         ctx.stats_reset()
-        elapsed, result = run_sharded(prob, args.steps, args.warmup, exchange, barrier, depth)
+        elapsed, result = run_sharded(prob, args.steps, args.warmup, (exchange_begin, exchange_end), barrier, depth)
         elapsed = allmax(elapsed)
         pipe_ms = accum_stats()
         main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
         ctx.stats_reset()
         ex_steps = max(2, args.steps // 4)
-        ex_elapsed, _ = run_sharded(prob, ex_steps, 1, exchange, barrier, 1)
+        ex_elapsed, _ = run_sharded(prob, ex_steps, 1, (exchange_begin, exchange_end), barrier, 1)
         ex_elapsed = allmax(ex_elapsed)
         excl_ms = accum_stats()
         e_tot = gather_e(prob.e_local)
@@ -495,14 +516,14 @@ def main():
         t_pre = time.perf_counter(); head.bases.precompute(16); precompute_s = time.perf_counter() - t_pre
 
     ctx.stats_reset()
-    elapsed, result = run_sharded(head, args.steps, args.warmup, exchange, barrier, depth)
+    elapsed, result = run_sharded(head, args.steps, args.warmup, (exchange_begin, exchange_end), barrier, depth)
     elapsed = allmax(elapsed)
     pipe_ms = accum_stats()
     main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
     # the same MSM with ONE in flight: latency of a single multi-exponentiation and the exclusive duration of its accumulation kernel
     ctx.stats_reset()
     ex_steps = max(4, args.steps // 2)
-    ex_elapsed, _ = run_sharded(head, ex_steps, 1, exchange, barrier, 1)
+    ex_elapsed, _ = run_sharded(head, ex_steps, 1, (exchange_begin, exchange_end), barrier, 1)
     ex_elapsed = allmax(ex_elapsed)
     excl_ms = accum_stats()
 
@@ -546,7 +567,7 @@ def main():
             t_pre = time.perf_counter(); pre.bases.precompute(16); pre_s = time.perf_counter() - t_pre
             ctx.stats_reset()
             k2 = max(4, args.steps // 2)
-            el2, res2 = run_sharded(pre, k2, 2, exchange, barrier, depth)
+            el2, res2 = run_sharded(pre, k2, 2, (exchange_begin, exchange_end), barrier, depth)
             extras["resident_key_window_multiples"] = {"ms_per_step": el2 / k2 * 1e3, "points_per_s": n * k2 / el2, "table_memory_factor": 16, "build_once_s": pre_s,
                                                        "k_accum28_avg_ms_pipelined": accum_stats(), "same_result": bool(np.array_equal(res2, result))}
             pre.bases.free()
@@ -600,7 +621,7 @@ def main():
             extras["g2_msm_2p18_ms"] = dtg * 1e3
             extras["g2_msm_2p18_points_per_s"] = n2 / dtg
             g2p = Head(); g2p.group = 2; g2p.d_s = d_s2; g2p.n = n2; g2p.bases = b2
-            elg, resg = run_sharded(g2p, 9, 2, exchange, barrier, depth)          # the same MSM with `depth` in flight, like the headline
+            elg, resg = run_sharded(g2p, 9, 2, (exchange_begin, exchange_end), barrier, depth)          # the same MSM with `depth` in flight, like the headline
             extras["g2_msm_2p18_pipelined_ms"] = elg / 9 * 1e3
             extras["g2_msm_2p18_pipelined_points_per_s"] = n2 * 9 / elg
             extras["g2_msm_2p18_pipelined_same_result"] = bool(np.array_equal(resg, res2))
@@ -634,7 +655,7 @@ def main():
             prob = ShardedMsm(ctx, v, torch, dev, group, 1 << lg, world, rank, seed=55 + group)
             ctx.stats_reset()
             k5 = 2 * depth
-            el5, res5 = run_sharded(prob, k5, depth, exchange, barrier, depth)      # warm-up = one MSM per work slot: their multi-GB workspaces are allocated on first use
+            el5, res5 = run_sharded(prob, k5, depth, (exchange_begin, exchange_end), barrier, depth)      # warm-up = one MSM per work slot: their multi-GB workspaces are allocated on first use
             el5 = allmax(el5)
             e5 = gather_e(prob.e_local)
             tag = "g1" if group == 1 else "g2"
