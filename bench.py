@@ -113,12 +113,14 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
     wit = ctx.host_register(np.ascontiguousarray(wit))                     # page-locked once (vsp_host_register): the witness copy is an asynchronous DMA
     pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)          # warm-up (twiddles, workspaces)
-    reps = 5
+    reps = 10
     ctx.stats_reset()
-    t0 = time.perf_counter()
+    each = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         pa, pb, pc, proof = v.groth16_prove(ctx, dcs, pk, wit, r, s_)
-    dt = (time.perf_counter() - t0) / reps
+        each.append(time.perf_counter() - t0)
+    dt = float(np.median(each))                              # the median: one proof in a few hundred takes twice as long (a 14 ms reading in a 5-proof mean)
     phases = {k: ctx.stat("prove_" + k + "_ms") / reps for k in ("launch", "host_overlap", "wait", "assembly")}
     # throughput mode: contexts are independent and keys / constraint systems are plain device resources, so two host threads
     # with a context each prove concurrently over ONE resident key (the tails of one proof overlap the bulk of the other)
@@ -150,7 +152,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
            f"prove_2p{log_m}_constraints": nc, f"generate_2p{log_m}_gpu_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
            f"prove_2p{log_m}_phase_ms": phases,
-           f"prove_2p{log_m}_two_contexts_ms_per_proof": dt2 * 1e3, f"prove_2p{log_m}_two_contexts_proofs_per_s": 1.0 / dt2,
+           f"prove_2p{log_m}_ms_mean_max": [float(np.mean(each)) * 1e3, float(np.max(each)) * 1e3], f"prove_2p{log_m}_two_contexts_ms_per_proof": dt2 * 1e3, f"prove_2p{log_m}_two_contexts_proofs_per_s": 1.0 / dt2,
            f"prove_2p{log_m}_two_contexts_same_proof": bool(same)}
     # the reference's vote phase around the same proof (common.hpp:1131-1145): encrypt<elgamal_verifiable> (ciphertext of the 25
     # message blocks on the host while the GPU proves, proof with the SAVER addend) + rerandomize; verified by the oracle's pairing
