@@ -220,18 +220,40 @@ int vsp_saver_rerandomize(vsp_ctx *ctx, const vsp_saver_pk *spk, const uint64_t 
     auto fD = std::async(std::launch::async, [&]() { return xyzz_mul_scalar(xyzz_from_affine(d2), z2, 255); });
     Affine<HFp> a_in = host_load_g1(A);
     auto fA = std::async(std::launch::async, [&]() { return xyzz_mul_scalar(xyzz_from_affine(a_in), z1, 255); });
+    // ct_i += r' X_i: n + 2 fixed-base multiplications (64 mixed additions each), the upper half on another thread; all the G1
+    // results of the call (n + 2 ciphertext elements, A, C) share ONE field inversion (prefix products of ZZZ) -- a Fermat
+    // inversion per element was a third of the call
+    std::vector<XYZZ<HFp>> pts(n + 4);
+    auto ct_range = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) { XYZZ<HFp> t = spk->X[i].mul_scalar(rp); xyzz_madd(t, host_load_g1(ct + 12 * i)); pts[i] = t; }
+    };
+    const size_t mid = (n + 2) / 2;
+    auto fC = std::async(std::launch::async, [&]() { ct_range(mid, n + 2); });
     XYZZ<HFp> zzA = xyzz_mul_scalar(xyzz_from_affine(a_in), zz4, 255);
-    for (size_t i = 0; i < n + 2; i++) {                       // ct_i += r' X_i
-        XYZZ<HFp> t = spk->X[i].mul_scalar(rp);
-        xyzz_madd(t, host_load_g1(ct + 12 * i));
-        host_store_g1(ct + 12 * i, xyzz_to_affine(t));
-    }
+    ct_range(0, mid);
     XYZZ<HFp> nC = spk->P2.mul_scalar(rp);
     xyzz_add(nC, zzA);
     xyzz_madd(nC, host_load_g1(C));
+    fC.get();
+    pts[n + 2] = fA.get(); pts[n + 3] = nC;
+    {
+        std::vector<HFp> pre(pts.size());
+        HFp run = HFp::one();
+        for (size_t i = 0; i < pts.size(); i++) { pre[i] = run; if (!is_inf(pts[i])) run = mul(run, pts[i].ZZZ); }
+        HFp ri = inv(run);
+        for (size_t i = pts.size(); i-- > 0;) {
+            Affine<HFp> q; q.x = HFp::zero(); q.y = HFp::zero();
+            if (!is_inf(pts[i])) {
+                HFp zi3 = mul(ri, pre[i]);                               // 1 / ZZZ_i
+                ri = mul(ri, pts[i].ZZZ);
+                HFp zi = mul(zi3, pts[i].ZZ), zi2 = sqr(zi);
+                q.x = mul(pts[i].X, zi2); q.y = mul(pts[i].Y, zi3);
+            }
+            host_store_g1(i < n + 2 ? ct + 12 * i : (i == n + 2 ? A : C), q);
+        }
+    }
     XYZZ<HFp2> nB = fB.get(); { XYZZ<HFp2> w = fD.get(); xyzz_add(nB, w); }
-    XYZZ<HFp> nA = fA.get();
-    host_store_g1(A, xyzz_to_affine(nA)); host_store_g2(B, xyzz_to_affine(nB)); host_store_g1(C, xyzz_to_affine(nC));
+    host_store_g2(B, xyzz_to_affine(nB));
     if (proof_out) { vsp_g1_compress(A, proof_out); vsp_g2_compress(B, proof_out + 48); vsp_g1_compress(C, proof_out + 144); }
     return VSP_OK;
 }
