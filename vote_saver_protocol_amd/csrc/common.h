@@ -55,6 +55,7 @@ struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };
 struct MsmWork {
     static constexpr size_t PINNED_BYTES = 128 * 1024;
     bool inited = false, own_stream = false, active = false, empty = false;
+    bool dimbits = false;                  // layout of the window results of the last launch (msm_impl.inc k_dimbits / k_dimweight)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
