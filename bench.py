@@ -362,6 +362,8 @@ def main():
         ctx.set_option("msm_split", int(os.environ["VSP_MSM_SPLIT"]))      # experiment knob: points per bucket part
     if os.environ.get("VSP_MSM_GLV"):
         ctx.set_option("msm_glv", int(os.environ["VSP_MSM_GLV"]))          # experiment knob: 2 forces the endomorphism split at any size
+    for kv in [x for x in os.environ.get("VSP_OPTS", "").split(",") if x]:      # experiment knob: VSP_OPTS="name=value,name=value"
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.prove_h_first >= 0:
         ctx.set_option("prove_h_first", args.prove_h_first)
     depth = 1 if args.no_pipeline else args.pipeline_depth
