@@ -70,7 +70,10 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
  * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
  * "prove_early_assembly" (default 1: s*A and r*B1 are computed on the host as soon as those two results arrive, inside the wait for
- * the H chain), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library); diagnostics:
+ * the H chain), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library), "msm_dimbits" (1 / 0: the last
+ * step of the bucket reduction as plain subset sums folded by the host's doubling chain / as weighted sums on the GPU; default by group),
+ * "msm_slot_normal_priority" (1 before the first use of a work slot: its stream gets the context's priority instead of the lowest --
+ * faster single proofs, slower independent multi-exponentiations in flight); diagnostics:
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
  * multi-exponentiation -- a blocking read-back). */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
