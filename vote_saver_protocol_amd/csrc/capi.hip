@@ -139,6 +139,7 @@ void vsp_destroy(vsp_ctx *ctx) {
     for (DevBuf *b : bufs) free_buf(*b);
     msm_free_slots(ctx);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1); hipEventDestroy(ctx->ev_aux);
+    for (hipStream_t ps : ctx->prove_streams) if (ps) hipStreamDestroy(ps);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

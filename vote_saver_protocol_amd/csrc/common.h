@@ -56,7 +56,8 @@ struct MsmWork {
     static constexpr size_t PINNED_BYTES = 128 * 1024;
     bool inited = false, own_stream = false, active = false, empty = false;
     bool dimbits = false;                  // layout of the window results of the last launch (msm_impl.inc k_dimbits / k_dimweight)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream launches queue on: the slot's own one, or a borrowed one (msm_slot_use_stream)
+    hipStream_t own = nullptr;             // the slot's own stream (slots 1..), created when first needed
     hipEvent_t ev0 = nullptr, ev1 = nullptr, done = nullptr, plan_ready = nullptr;
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres, medium, redo;
@@ -83,6 +84,7 @@ struct vsp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream in use
     hipStream_t own_stream = nullptr;   // created by vsp_create
+    hipStream_t prove_streams[2] = {nullptr, nullptr};      // the prover's two witness chains (prover.hip), created on first use
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_aux = nullptr;
     std::string err;
     std::map<std::string, double> stats;
@@ -203,6 +205,8 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
 int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);
+int msm_slot_use_stream(vsp_ctx *ctx, unsigned slot, hipStream_t stream_or_null);
+int msm_make_slot_stream(vsp_ctx *ctx, hipStream_t *out);
 void msm_drain_slots(vsp_ctx *ctx);
 // d_flag: one device word, zeroed by the caller; bit 0 = coordinate >= p, bit 1 = point off the curve (only when check_curve)
 int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);

@@ -143,6 +143,7 @@ int prove_with_overlap(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const
         msm_drain_slots(ctx);
         ctx->err = keep;
     }
+    for (unsigned k = 1; k <= 4; k++) (void)msm_slot_use_stream(ctx, k, nullptr);      // the slots go back to their own streams
     // the witness does not outlive the call in device memory
     if (ctx->pr_z.p) hipMemsetAsync(ctx->pr_z.p, 0, ctx->pr_z.cap, ctx->stream);
     return rc;
@@ -193,6 +194,19 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     // multi-exponentiation, the longest dependent chain, on the context's stream; (3) the four multi-exponentiations over the
     // witness -- independent of witness_map -- on the low-priority slots 1-4, filling the GPU around (2).  A_query, B_query(G1)
     // and B_query(G2) share one digit sort / bucket plan (same scalars) when their bases are precomputed alike.
+    // The four witness multi-exponentiations run as TWO chains, on two streams the prover owns (lowest priority, like the work slots' own
+    // streams, which stay free for callers that pipeline independent multi-exponentiations): A_query then B_query(G1) on one, B_query(G2)
+    // -- which waits for A_query's digit sort, the plan the three share -- then L_query on the other.  Measured at 2^20 constraints on one
+    // box: 6.5 ms per proof against 7.2-7.6 ms with one stream per multi-exponentiation, the same 170 / 190 proofs/s with two / three
+    // contexts; the other pairings lose (A,B2 | B1,L: 7.8 ms; all four on one stream: 7.3 ms).  Fewer concurrent witness chains leave the
+    // transforms and the H accumulation -- the critical chain -- alone for longer.  Option "prove_witness_streams" = 0: the
+    // slots' own streams.
+    long wstreams = 1; { auto it = ctx->opts.find("prove_witness_streams"); if (it != ctx->opts.end()) wstreams = it->second; }
+    if (wstreams) {
+        for (int k = 0; k < 2; k++) if (!ctx->prove_streams[k]) VSP_TRY(msm_make_slot_stream(ctx, &ctx->prove_streams[k]));
+        VSP_TRY(msm_slot_use_stream(ctx, 1, ctx->prove_streams[0])); VSP_TRY(msm_slot_use_stream(ctx, 2, ctx->prove_streams[0]));
+        VSP_TRY(msm_slot_use_stream(ctx, 3, ctx->prove_streams[1])); VSP_TRY(msm_slot_use_stream(ctx, 4, ctx->prove_streams[1]));
+    }
     XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
     VSP_TRY(msm_slot_census(ctx, 1, dz, nv + 1));
     VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
