@@ -44,6 +44,25 @@ def test_prove_bit_exact_vs_oracle(ctx, cref, nc, ni):
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
 
 
+@pytest.mark.parametrize("option,value", [("prove_witness_streams", 0), ("msm_dimbits", 0), ("msm_dimbits", 1), ("prove_early_assembly", 0),
+                                          ("prove_plan_first", 1), ("prove_h_first", 0), ("msm_slot_normal_priority", 1), ("msm_glv", 0)])
+def test_prove_is_the_same_proof_under_every_scheduling_option(cref, option, value):
+    """the documented tuning options (include/vsp.h) change how the work is queued or which kernel variant folds the buckets, never the
+    result: the same proof bytes as the oracle's, on a context of its own so that stream-creation options take effect"""
+    c = v.Context(0)
+    try:
+        c.set_option(option, value)
+        for precompute in (None, "all"):
+            cs, wit, kp, dcs, pk, q, r, s = build(c, cref, 1500, 7, seed=31, precompute=precompute)
+            for _ in range(2):                                  # twice: the second call reuses warm workspaces and cached censuses
+                A, B, Cc, proof = v.groth16_prove(c, dcs, pk, wit, r, s)
+                eA, eB, eC = kp.prove(wit, r, s)
+                assert np.array_equal(A, eA) and np.array_equal(B, eB) and np.array_equal(Cc, eC), (option, value, precompute)
+            pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("mode", ["all", "mixed"])
 def test_prove_with_precomputed_key_bit_exact(ctx, cref, mode):
     cs, wit, kp, dcs, pk, q, r, s = build(ctx, cref, 700, 4, seed=11, precompute=mode)
