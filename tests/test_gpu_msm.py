@@ -472,3 +472,39 @@ def test_msm_g2_2p21_config5_shard_plain_bases(ctx, cref):
         assert np.array_equal(part, cref.msm_g2(host_b, ss[at:at + m]))
     finally:
         B.free(); ctx.dfree(d_b); ctx.dfree(d_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option,value", [("msm_dimbits", 0), ("msm_dimbits", 1), ("msm_dimsum_lanes", 8), ("msm_dimsum_lanes", 16),
+                                          ("msm_dimsum_lanes", 32), ("msm_dimsum_lanes", 64), ("msm_glv", 0), ("msm_glv", 2), ("msm_fp28", 0)])
+def test_msm_same_result_under_every_kernel_variant_option(cref, option, value):
+    """the tuning options of include/vsp.h pick kernel variants (lanes per bucket-digit sum, bit-decomposed or weighted last step of the
+    bucket reduction, endomorphism split, 28-bit or 12 x 32-bit accumulation): every variant gives the oracle's point, on plain and on
+    precomputed bases, dense and boolean-heavy scalars, both groups"""
+    c = v.Context(0)
+    try:
+        c.set_option(option, value)
+        for group, n in ((1, 3000), (1, 40000), (2, 2500), (2, 33000)):
+            if (group, n) not in _VARIANT_CASES:               # inputs and the oracle's answers once for all options
+                ks = rand_fr_array(n, seed=600 + n)
+                bases = (cref.g1_batch_mul_gen if group == 1 else cref.g2_batch_mul_gen)(ks)
+                dense = rand_fr_array(n, seed=700 + n)
+                sparse = dense.copy(); m = np.arange(n) % 10 != 0; sparse[m] = 0; sparse[m, 0] = (np.arange(n)[m] & 1).astype(np.uint64)
+                ref = cref.msm_g1 if group == 1 else cref.msm_g2
+                _VARIANT_CASES[(group, n)] = (bases, [(ss, ref(bases, ss, mixed=True)) for ss in (dense, sparse)])
+            bases, cases = _VARIANT_CASES[(group, n)]
+            for precompute in (False, True):
+                B = c.upload_bases(bases, group)
+                if precompute:
+                    B.precompute(0)
+                for ss, exp in cases:
+                    d_s = c.to_device(ss)
+                    got, _ = B.msm(d_s)
+                    c.dfree(d_s)
+                    assert np.array_equal(got, exp), (option, value, group, n, precompute)
+                B.free()
+    finally:
+        c.close()
+
+
+_VARIANT_CASES = {}
