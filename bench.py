@@ -8,13 +8,18 @@ scalars/points, bit-exact vs multiexp), whole job, inputs resident in HBM, PLAIN
 (G1) / 288-byte (G2) Jacobian partial sums and a local fold.
 
     python bench.py --gpus 1 --steps 20 --warmup 3                       # headline: 2^20 G1 points per GPU ("weak")
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...                                         # N > 1 without RANK in the environment: this process starts
+                                                                         # `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+                                                                         # before anything touches the GPU and returns its exit code
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # the driver's form
     ... bench.py --gpus N --scaling strong --total-log-n 26 --group g1    # BASELINE config 5: ONE 2^26-point problem, rank g holds chunk g
     ... bench.py --gpus N --scaling strong --total-log-n 24 --group g2
 
 Without --scaling strong the per-GPU work is fixed (2^20 points per rank, "weak"); the default run additionally measures
-BASELINE config 5 (2^26 G1 + 2^24 G2 points split over the N ranks) as `extras.config5`, so the driver's N = 1, 2, 4, 8 lines carry
-the strong-scaling curve of that fixed problem next to the headline.
+BASELINE config 5 (2^26 G1 + 2^24 G2 points split over the N ranks) -- `scaling_strong` at the top level of the line (and
+`extras.config5` in full) -- so the driver's N = 1, 2, 4, 8 lines carry the strong-scaling curve of that fixed problem next to the
+headline.  The sharded multi-exponentiation itself is the package's (vote_saver_protocol_amd/sharded.py); this file only generates the
+synthetic shards, times and verifies.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (bucket accumulation, k_accum28) with HIP events recorded on
 the launch stream, from a leg with ONE multi-exponentiation in flight (so nothing else shares the GPU with the kernel; the
@@ -23,8 +28,11 @@ the reference build) on the same inputs, `cpu_baseline_all_cores` the same split
 argument of multiexp) -- reported baselines only.  Nothing here reads /root/reference.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -231,8 +239,52 @@ def host_cores():
 
 
 def shard_bounds(total, world, rank):
-    """contiguous point chunk of rank `rank`: [lo, hi)"""
-    return rank * total // world, (rank + 1) * total // world
+    """contiguous point chunk of rank `rank`: [lo, hi) -- the package's rule (vote_saver_protocol_amd/sharded.py)"""
+    from vote_saver_protocol_amd.sharded import shard_bounds as sb
+    return sb(total, world, rank)
+
+
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT initialising the HIP runtime (the launcher must not touch the GPU before it starts its
+    ranks): the KFD topology nodes that have SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology is
+    not readable (the ranks then check for themselves)."""
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return 0 if not os.path.exists("/dev/kfd") else None
+    n = 0
+    for f in nodes:
+        try:
+            for line in open(f):
+                k, _, val = line.partition(" ")
+                if k == "simd_count" and int(val) > 0:
+                    n += 1
+        except OSError:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        if os.environ.get(var, "") != "":
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip() != ""]))
+    return n
+
+
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` started as a plain process: run the N ranks as a child `torch.distributed.run` (one process per GPU, RCCL
+    rendezvous on 127.0.0.1) and return its exit code.  This process has not imported torch and never touches HIP: nothing that has
+    initialised the GPU is ever replaced or forked.  Rank 0 of the child writes the JSON line to the stdout it inherits from here."""
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus and not args.allow_shared_gpu:
+        print(f"bench.py: --gpus {args.gpus} but {have} GPU(s) are visible on this machine; nothing was launched "
+              "(--allow-shared-gpu --backend gloo rehearses several ranks on one GPU)", file=sys.stderr)
+        return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def dot_mod_r_device(torch, k64, s4):
@@ -247,12 +299,13 @@ def dot_mod_r_device(torch, k64, s4):
     return total % R_MOD
 
 
-class ShardedMsm:
-    """One MSM problem of `total` points of group 1 / 2 split by contiguous chunk over the ranks; every rank builds and keeps only
-    its chunk (bases k_i * generator with 64-bit k_i -- full-size curve points; the small k only makes the checker's sum cheap --
-    and uniform 254-bit scalars, both generated on the device)."""
+class ShardProblem:
+    """Synthetic input of one MSM problem of `total` points of group 1 / 2 split by contiguous chunk over the ranks; every rank builds
+    and keeps only its chunk (bases k_i * generator with 64-bit k_i -- full-size curve points; the small k only makes the checker's sum
+    cheap -- and uniform 254-bit scalars, both generated on the device).  The multi-exponentiation over it is the package's
+    vote_saver_protocol_amd.sharded.ShardedMsm."""
 
-    def __init__(self, ctx, v, torch, dev, group, total, world, rank, seed):
+    def __init__(self, ctx, v, torch, dev, group, total, world, rank, seed, sample=0):
         self.ctx, self.v, self.group, self.total, self.world = ctx, v, group, total, world
         lo, hi = shard_bounds(total, world, rank)
         self.n = n = hi - lo
@@ -265,6 +318,11 @@ class ShardedMsm:
         d_b = v.fixed_base_mul(ctx, k4, n, group)
         del k4
         self.bases = ctx.bases_from_device(d_b, n, group)
+        self.sample = None
+        if rank == 0 and sample:                                   # a bounded host copy of the first points: the CPU baseline's input
+            m = min(n, sample)
+            hb = np.zeros((m, 12 * group), np.uint64); ctx.d2h(hb, d_b)
+            self.sample = (hb, self.d_s[:m].cpu().numpy().view(np.uint64).copy())
         ctx.dfree(d_b)
         self.e_local = dot_mod_r_device(torch, k64, self.d_s)
         del k64
@@ -274,36 +332,14 @@ class ShardedMsm:
 
 
 def run_sharded(problem, steps, warmup, exchange, barrier, depth):
-    """`steps` MSMs over the rank's chunk + exchange, `depth` in flight; returns (seconds for `steps`, last folded result).
-    exchange = (begin, end): the exchange of step k completes while step k + 1's multi-exponentiation is awaited"""
-    x_begin, x_end = exchange
-    sl = (1, 2, 4, 5)[:max(1, min(4, depth))]
-    D = len(sl)
-
-    def go(k_steps):
-        res = None; pending = None
-        if D > 1:
-            for k in range(min(D - 1, k_steps)):
-                problem.bases.msm_launch(sl[k % D], problem.d_s)
-        for k in range(k_steps):
-            if D == 1:
-                rec = problem.bases.msm_jacobian(problem.d_s)
-            else:
-                if k + D - 1 < k_steps:
-                    problem.bases.msm_launch(sl[(k + D - 1) % D], problem.d_s)
-                rec = problem.bases.msm_finish_jacobian(sl[k % D])
-            h = x_begin(rec, problem.group, k & 1)
-            if pending is not None:
-                res = x_end(pending)
-            pending = h
-        if pending is not None:
-            res = x_end(pending)
-        return res
-
+    """`steps` MSMs over the rank's chunk + exchange, `depth` in flight (vote_saver_protocol_amd.sharded.ShardedMsm.run: the exchange
+    of step k completes while step k + 1's multi-exponentiation is awaited); returns (seconds for `steps`, last folded result)"""
+    from vote_saver_protocol_amd.sharded import ShardedMsm
+    job = ShardedMsm(problem.bases, exchange)
     if warmup:
-        go(warmup)
+        job.run(problem.d_s, warmup, depth)
     barrier(); t0 = time.perf_counter()
-    res = go(steps)
+    res = job.run(problem.d_s, steps, depth)
     barrier()
     return time.perf_counter() - t0, res
 
@@ -330,7 +366,18 @@ def main():
     ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend of the exchange step: nccl = RCCL over xGMI (device buffers); gloo = host buffers (rehearsals)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank g uses GPU g mod (GPUs present); forces --backend gloo (RCCL refuses two ranks on one GPU)")
     args = ap.parse_args()
+    if args.allow_shared_gpu:
+        args.backend = "gloo"
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    # N > 1 started as a plain process (no RANK in the environment): start the ranks as a child process BEFORE anything touches the GPU
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner, for one) is sent to stderr
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -349,16 +396,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()                    # counting devices does not initialise the runtime
+    if n_dev < 1 or (n_dev < world and not args.allow_shared_gpu):
+        if rank == 0:
+            print(f"bench.py: {world} rank(s) need {world} GPU(s), {n_dev} visible (this path has no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ                     # launched by torch.distributed.run (also with one rank: same code path)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the bookkeeping collectives (max of timings, checker sums) live
 
-    ctx = v.Context(local_rank)
+    ctx = v.Context(dev_index)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
     if args.window_bits:
@@ -373,31 +430,12 @@ def main():
         ctx.set_option("prove_h_first", args.prove_h_first)
     depth = 1 if args.no_pipeline else args.pipeline_depth
 
-    # exchange step: one Jacobian record per rank (144 B G1 / 288 B G2), all-gathered over RCCL, folded locally.  Two buffers per group:
-    # the all-gather of step k is in flight while the host waits for the multi-exponentiation of step k + 1 (exchange_begin / _end),
-    # so its latency -- a small kernel that has to find a wave slot on a GPU full of accumulation waves, ~0.2 ms -- stays off the step time
-    rec_dev = {g: [torch.zeros(18 * g, dtype=torch.int64, device=dev) for _ in range(2)] for g in (1, 2)}
-    all_dev = {g: [torch.zeros(18 * g * world, dtype=torch.int64, device=dev) for _ in range(2)] for g in (1, 2)}
-    x_stream = torch.cuda.Stream(device=dev) if use_dist else None
-
-    def exchange_begin(rec, group=1, buf=0):
-        if not use_dist:
-            return (None, rec, group, buf)
-        with torch.cuda.stream(x_stream):
-            rec_dev[group][buf].copy_(torch.from_numpy(rec.view(np.int64)))
-            work = dist.all_gather_into_tensor(all_dev[group][buf], rec_dev[group][buf], async_op=True)
-        return (work, None, group, buf)
-
-    def exchange_end(h):
-        work, rec, group, buf = h
-        w = 18 * group
-        if work is not None:
-            work.wait()
-            with torch.cuda.stream(x_stream):
-                recs = all_dev[group][buf].cpu().numpy().view(np.uint64).reshape(world, w)
-        else:
-            recs = rec.reshape(1, w)
-        return v.fold_jacobian(ctx, recs, group)            # local fold + affine normalisation
+    # exchange step (vote_saver_protocol_amd/sharded.py): one Jacobian record per rank (144 B G1 / 288 B G2), all-gathered over RCCL from
+    # device buffers on a stream of its own, folded locally.  Two buffers per group: the all-gather of step k is in flight while the host
+    # waits for the multi-exponentiation of step k + 1, so its latency -- a small kernel that has to find a wave slot on a GPU full of
+    # accumulation waves, ~0.2 ms -- stays off the step time
+    exchange = v.TorchExchange(ctx, dev) if use_dist else v.LocalExchange(ctx)
+    ranks_seen = exchange.ranks_seen()
 
     def barrier():
         if use_dist:
@@ -407,17 +445,17 @@ def main():
     def allmax(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def gather_e(e_local):
-        e_dev = torch.from_numpy(limbs(e_local, 4).view(np.int64)).to(dev)
         if not use_dist:
             return e_local % R_MOD
-        e_all = torch.zeros(4 * world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(e_all, e_dev)
-        rows = e_all.cpu().numpy().view(np.uint64).reshape(world, 4)
+        e_dev = torch.from_numpy(limbs(e_local, 4).view(np.int64)).to(coll_dev)
+        parts = [torch.zeros(4, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(parts, e_dev)
+        rows = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, 4)
         return sum(int(x) for x in to_ints(rows).tolist()) % R_MOD
 
     cref = o = gens = None
@@ -429,6 +467,35 @@ def main():
 
     def expected_point(group, e_tot):                        # rank 0: (sum_i k_i s_i) * generator by the oracle's scalar multiplication
         return (cref.g1_mul if group == 1 else cref.g2_mul)(gens[group], limbs(e_tot, 4))
+
+    def cpu_baseline_legs(group, host_b, host_s, gpu_result=None):
+        """rank 0, any N: the reference algorithm on the host cores of this box -- the oracle's serial BDLO12 (1 thread, as the reference
+        builds), then the same work cut in `cores` chunks (multiexp's chunks argument), one thread per core.  Bounded sample."""
+        from concurrent.futures import ThreadPoolExecutor
+        m = host_b.shape[0]
+        fn = cref.msm_g1 if group == 1 else cref.msm_g2
+        G = o.G1 if group == 1 else o.G2
+        to_l, from_l = (o.g1_to_limbs, o.g1_from_limbs) if group == 1 else (o.g2_to_limbs, o.g2_from_limbs)
+        name = "G1" if group == 1 else "G2"
+        tc = time.perf_counter()
+        ref = fn(host_b, host_s)
+        dt = time.perf_counter() - tc
+        one = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
+               "sample": f"one {m}-point {name} MSM (serial BDLO12 restatement, oracle/vsp_ref.c), {dt:.1f} s",
+               "matches_gpu_result": bool(np.array_equal(ref, gpu_result)) if gpu_result is not None else None}
+        cores = host_cores()
+        cuts = [shard_bounds(m, cores, i) for i in range(cores)]
+        tc = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:                 # the C call releases the GIL: one chunk per core
+            parts = list(ex.map(lambda ab: fn(host_b[ab[0]:ab[1]], host_s[ab[0]:ab[1]]), cuts))
+        acc = None
+        for q in parts:
+            acc = q if acc is None else np.array(to_l(G.add(from_l(acc), from_l(q))), dtype=np.uint64)
+        dta = time.perf_counter() - tc
+        allc = {"value": m / dta, "unit": "points/s", "cores": cores, "kind": "port",
+                "sample": f"the same {m}-point {name} MSM in {cores} chunks, one thread per host core, partial sums added ({dta:.2f} s)",
+                "matches_serial_result": bool(np.array_equal(acc, ref))}
+        return one, allc
 
     def accum_stats():
         ms, launches = ctx.stat("msm_accum_ms"), ctx.stat("msm_accum_launches")
@@ -475,29 +542,34 @@ def main():
         group = 1 if args.group == "g1" else 2
         lg_total = args.total_log_n or (26 if group == 1 else 24)
         total = 1 << lg_total
-        prob = ShardedMsm(ctx, v, torch, dev, group, total, world, rank, seed=77 + group)
+        prob = ShardProblem(ctx, v, torch, dev, group, total, world, rank, seed=77 + group,
+                            sample=0 if args.no_cpu_baseline else (1 << 20 if group == 1 else 1 << 17))
         ctx.stats_reset()
-        elapsed, result = run_sharded(prob, args.steps, args.warmup, (exchange_begin, exchange_end), barrier, depth)
+        elapsed, result = run_sharded(prob, args.steps, args.warmup, exchange, barrier, depth)
         elapsed = allmax(elapsed)
         pipe_ms = accum_stats()
         main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
         ctx.stats_reset()
         ex_steps = max(2, args.steps // 4)
-        ex_elapsed, _ = run_sharded(prob, ex_steps, 1, (exchange_begin, exchange_end), barrier, 1)
+        ex_elapsed, _ = run_sharded(prob, ex_steps, 1, exchange, barrier, 1)
         ex_elapsed = allmax(ex_elapsed)
         excl_ms = accum_stats()
         e_tot = gather_e(prob.e_local)
         if rank == 0:
             verified = bool(np.array_equal(result, expected_point(group, e_tot)))
+            if prob.sample is not None:                      # every N: the CPU path timed on this box's host cores in the same run
+                cpu_baseline, cpu_all = cpu_baseline_legs(group, prob.sample[0], prob.sample[1])
+        barrier()
         rl, rv = roofline_of(group, prob.n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
         out = {"metric": f"{args.group.upper()} MSM points/sec, one 2^{lg_total}-point problem sharded over the GPUs (BASELINE config 5)",
                "value": total * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                "config": {"workload": f"one 2^{lg_total}-point BLS12-381 {args.group.upper()} Pippenger MSM, plain bases k_i*G (64-bit k_i), uniform 254-bit scalars, "
-                                      f"resident in HBM; rank g holds the contiguous chunk g of {world}; one RCCL all-gather of {144 * group}-byte Jacobian records + local fold per MSM",
-                          "total_points": total, "points_per_gpu": prob.n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth},
+                                      f"resident in HBM; rank g holds the contiguous chunk g of {world}; one all-gather ({exchange.backend}) of {144 * group}-byte Jacobian records + local fold per MSM",
+                          "total_points": total, "points_per_gpu": prob.n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth,
+                          "exchange_backend": exchange.backend, "ranks_seen_by_collective": ranks_seen, "gpus_visible": n_dev},
                "verified_bit_exact": verified, "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3, "roofline": rl, "roofline_valu": rv,
-               "cpu_baseline": None}
+               "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all}
         if rank == 0:
             os.write(real_stdout, (json.dumps(out) + "\n").encode())
         prob.free(); ctx.close()
@@ -525,14 +597,14 @@ def main():
         t_pre = time.perf_counter(); head.bases.precompute(16); precompute_s = time.perf_counter() - t_pre
 
     ctx.stats_reset()
-    elapsed, result = run_sharded(head, args.steps, args.warmup, (exchange_begin, exchange_end), barrier, depth)
+    elapsed, result = run_sharded(head, args.steps, args.warmup, exchange, barrier, depth)
     elapsed = allmax(elapsed)
     pipe_ms = accum_stats()
     main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))
     # the same MSM with ONE in flight: latency of a single multi-exponentiation and the exclusive duration of its accumulation kernel
     ctx.stats_reset()
     ex_steps = max(4, args.steps // 2)
-    ex_elapsed, _ = run_sharded(head, ex_steps, 1, (exchange_begin, exchange_end), barrier, 1)
+    ex_elapsed, _ = run_sharded(head, ex_steps, 1, exchange, barrier, 1)
     ex_elapsed = allmax(ex_elapsed)
     excl_ms = accum_stats()
 
@@ -541,32 +613,18 @@ def main():
     if rank == 0:
         verified = bool(np.array_equal(result, expected_point(1, e_tot)))
 
-        if world == 1 and not args.no_cpu_baseline:
-            # reference algorithm on the host: serial BDLO12 (c = 16 at 2^20), same bases and scalars, 1 thread -- then the same work
-            # cut in `cores` chunks (multiexp's chunks argument) on every host core
+        if not args.no_cpu_baseline:
+            # every N (north_star: throughput at 1/2/4/8 GPUs next to the CPU path timed on the same box in the same run): the reference
+            # algorithm on the host, rank 0's own 2^log_n bases and scalars -- serial BDLO12 (c = 16 at 2^20), 1 thread, then all cores
             host_b = np.zeros((n, 12), np.uint64)
             ctx.d2h(host_b, d_bases_canon)
             m = min(n, 1 << 20)
-            tc = time.perf_counter()
-            ref = cref.msm_g1(host_b[:m], ss[:m])
-            dt = time.perf_counter() - tc
-            ok = bool(np.array_equal(ref, result)) if m == n else None
-            cpu_baseline = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
-                            "sample": f"one {m}-point G1 MSM (serial BDLO12 restatement, oracle/vsp_ref.c), {dt:.1f} s",
-                            "matches_gpu_result": ok}
-            from concurrent.futures import ThreadPoolExecutor
-            cores = host_cores()
-            cuts = [shard_bounds(m, cores, i) for i in range(cores)]
-            tc = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:             # the C call releases the GIL: one chunk per core
-                parts = list(ex.map(lambda ab: cref.msm_g1(host_b[ab[0]:ab[1]], ss[ab[0]:ab[1]]), cuts))
-            acc = None
-            for q in parts:
-                acc = q if acc is None else np.array(o.g1_to_limbs(o.G1.add(o.g1_from_limbs(acc), o.g1_from_limbs(q))), dtype=np.uint64)
-            dta = time.perf_counter() - tc
-            cpu_all = {"value": m / dta, "unit": "points/s", "cores": cores, "kind": "port",
-                       "sample": f"the same {m}-point G1 MSM in {cores} chunks, one thread per host core, partial sums added ({dta:.2f} s)",
-                       "matches_gpu_result": bool(np.array_equal(acc, result)) if m == n else None}
+            own = None
+            if world == 1 and m == n:
+                own = result
+            elif m == n:                                      # N > 1: rank 0's own partial sum, through the blocking single-GPU entry point
+                own, _ = head.bases.msm(d_s)
+            cpu_baseline, cpu_all = cpu_baseline_legs(1, host_b[:m], ss[:m], own)
             del host_b
 
         if world == 1 and not args.no_extras and not args.precompute:
@@ -576,7 +634,7 @@ def main():
             t_pre = time.perf_counter(); pre.bases.precompute(16); pre_s = time.perf_counter() - t_pre
             ctx.stats_reset()
             k2 = max(4, args.steps // 2)
-            el2, res2 = run_sharded(pre, k2, 2, (exchange_begin, exchange_end), barrier, depth)
+            el2, res2 = run_sharded(pre, k2, 2, exchange, barrier, depth)
             extras["resident_key_window_multiples"] = {"ms_per_step": el2 / k2 * 1e3, "points_per_s": n * k2 / el2, "table_memory_factor": 16, "build_once_s": pre_s,
                                                        "k_accum28_avg_ms_pipelined": accum_stats(), "same_result": bool(np.array_equal(res2, result))}
             pre.bases.free()
@@ -630,7 +688,7 @@ def main():
             extras["g2_msm_2p18_ms"] = dtg * 1e3
             extras["g2_msm_2p18_points_per_s"] = n2 / dtg
             g2p = Head(); g2p.group = 2; g2p.d_s = d_s2; g2p.n = n2; g2p.bases = b2
-            elg, resg = run_sharded(g2p, 9, 2, (exchange_begin, exchange_end), barrier, depth)          # the same MSM with `depth` in flight, like the headline
+            elg, resg = run_sharded(g2p, 9, 2, exchange, barrier, depth)          # the same MSM with `depth` in flight, like the headline
             extras["g2_msm_2p18_pipelined_ms"] = elg / 9 * 1e3
             extras["g2_msm_2p18_pipelined_points_per_s"] = n2 * 9 / elg
             extras["g2_msm_2p18_pipelined_same_result"] = bool(np.array_equal(resg, res2))
@@ -661,10 +719,10 @@ def main():
     if not args.no_config5 and not (world == 1 and args.no_extras):
         c5 = {"scaling": "strong", "n_gpus": world, "msms_in_flight": depth}
         for group, lg in ((1, args.config5_log_g1), (2, args.config5_log_g2)):
-            prob = ShardedMsm(ctx, v, torch, dev, group, 1 << lg, world, rank, seed=55 + group)
+            prob = ShardProblem(ctx, v, torch, dev, group, 1 << lg, world, rank, seed=55 + group)
             ctx.stats_reset()
             k5 = 2 * depth
-            el5, res5 = run_sharded(prob, k5, depth, (exchange_begin, exchange_end), barrier, depth)      # warm-up = one MSM per work slot: their multi-GB workspaces are allocated on first use
+            el5, res5 = run_sharded(prob, k5, depth, exchange, barrier, depth)      # warm-up = one MSM per work slot: their multi-GB workspaces are allocated on first use
             el5 = allmax(el5)
             e5 = gather_e(prob.e_local)
             tag = "g1" if group == 1 else "g2"
@@ -673,6 +731,8 @@ def main():
                        "verified": bool(np.array_equal(res5, expected_point(group, e5))) if rank == 0 else None}
             prob.free()
         extras["config5"] = c5
+        c5["exchange_backend"] = exchange.backend
+        c5["ranks_seen_by_collective"] = ranks_seen
 
     rl, rv = roofline_of(1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
     out = {
@@ -703,7 +763,19 @@ def main():
         "roofline_valu": rv,
         "cpu_baseline": cpu_baseline,
         "cpu_baseline_all_cores": cpu_all,
+        "exchange": {"backend": exchange.backend, "ranks_seen_by_collective": ranks_seen, "gpus_visible": n_dev,
+                     "records": "one Jacobian partial sum per rank and MSM (144 B G1 / 288 B G2), all-gathered, folded locally (vote_saver_protocol_amd/sharded.py)"},
     }
+    if "config5" in extras:
+        # BASELINE config 5 at the top level: ONE 2^26-point G1 and ONE 2^24-point G2 problem split over the N ranks of this run -- the driver's
+        # N = 1, 2, 4, 8 lines give the strong-scaling curve (north_star: >= 6x at 8 GPUs) from these two figures
+        c5 = extras["config5"]
+        out["scaling_strong"] = {"g1_points_per_s": c5["g1"]["points_per_s"], "g2_points_per_s": c5["g2"]["points_per_s"],
+                                 "g1_total_log_n": c5["g1"]["total_log_n"], "g2_total_log_n": c5["g2"]["total_log_n"],
+                                 "g1_ms_per_msm": c5["g1"]["ms_per_msm"], "g2_ms_per_msm": c5["g2"]["ms_per_msm"],
+                                 "verified": bool(c5["g1"]["verified"] and c5["g2"]["verified"]) if rank == 0 else None,
+                                 "ranks_seen_by_rccl": ranks_seen if exchange.backend == "nccl" else None,
+                                 "ranks_seen_by_collective": ranks_seen, "backend": exchange.backend, "n_gpus": world}
     if extras:
         out["extras"] = extras
         if "prove_2p20_proofs_per_s" in extras:      # the other half of BASELINE.json's metric, same run

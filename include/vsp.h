@@ -59,12 +59,20 @@ int vsp_synchronize(vsp_ctx *ctx);
 double vsp_get_stat(vsp_ctx *ctx, const char *name);
 void vsp_stats_reset(vsp_ctx *ctx);
 /* options: "bases_check_curve" (default 1: uploads verify y^2 = x^3 + b for every point; coordinates < p are always checked),
+ * "bases_check_subgroup" (the endomorphism split below relies on phi(P) = lambda P, which holds only in the order-r subgroup, while
+ * the curve equation also admits points with a cofactor component.  1, the default: an upload that would use the split checks
+ * phi(P) = lambda P for every point on the GPU (126 doublings + 11 additions per point, 20-30 ms for 2^20 G1 points, once per key);
+ * bases that fail keep the plain layout, over which sum k_i P_i is exact for ANY curve point -- as the reference's generic multiexp is
+ * -- and vsp_get_stat("bases_outside_subgroup") counts them.  2: every upload is checked and one that fails is refused with
+ * VSP_ERR_ARG.  0: never checked, and then never split unless "msm_glv" = 2.  Keys made by vsp_groth16_generate are multiples of the
+ * generators and need no check; the bases of one vsp_msm_g1 / vsp_msm_g2 call are never split, hence never checked),
  * "msm_census_sync" (1: every multi-exponentiation waits for its own 0/1 census before planning; default 0: a slot plans from the
  * count it saw for the previous vector of the same length -- the count steers window size and part length, never the result);
  * "msm_glv" (default 1: plain resident bases keep phi(P) = (beta x, y) = lambda P beside every P in the 28-bit-limb table -- 2 x 128
  * (G1) / 2 x 256 (G2) bytes per point -- and every scalar is split k = k1 + k2 lambda into two signed 127-bit halves: half as many windows,
  * i.e. half the bucket sets to reduce -- applied while the doubled table stays within 256 MB for G1 (2^20 points) / 128 MB for G2
- * (2^18 points): beyond that the measurements favour the plain layout; 2 forces it for any size, 0 before an upload keeps the plain layout);
+ * (2^18 points): beyond that the measurements favour the plain layout; 2 forces it for any size AND skips the subgroup check -- the caller
+ * vouches that every base is in the order-r subgroup, else results are wrong; 0 before an upload keeps the plain layout);
  * tuning knobs: "msm_window_bits" (0 = automatic), "msm_split" (bucket split threshold), "prove_h_first" (1: queue witness_map and
  * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
  * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
@@ -73,7 +81,11 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * the H chain), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library), "msm_dimbits" (1 / 0: the last
  * step of the bucket reduction as plain subset sums folded by the host's doubling chain / as weighted sums on the GPU; default by group),
  * "msm_slot_normal_priority" (1 before the first use of a work slot: its stream gets the context's priority instead of the lowest --
- * faster single proofs, slower independent multi-exponentiations in flight); diagnostics:
+ * faster single proofs, slower independent multi-exponentiations in flight), "ntt_fr29" (default 1: butterflies on
+ * 9 x 29-bit limbs; 0: the 8 x 32-bit kernel); diagnostics: every context checks its hand-laid-out field routines THROUGH the kernels
+ * that use them, against the generic kernels, on data the library generates itself -- vsp_get_stat "msm_fp28_selfcheck_g1" / "_g2"
+ * (first 28-bit table of a group) and "ntt_fr29_selfcheck" (first transform): 1 passed, -1 failed (the context then runs the generic
+ * kernels for its lifetime and vsp_last_error says so), 0 could not run;
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
  * multi-exponentiation -- a blocking read-back). */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
@@ -127,10 +139,20 @@ int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first
  * device memory before the launch and must not change until the finish. */
 int vsp_msm_launch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars);
 int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian);
+/* Same, but the record is left in DEVICE memory at d_out_jacobian (18 / 36 uint64) -- where the RCCL all-gather of the sharded
+ * multi-exponentiation reads it.  The record is completed on the host (the last c * W doublings of a multi-exponentiation
+ * are one dependent chain, ~50x faster on a CPU core than on a GPU lane), written to a pinned ring entry of the slot and copied by an
+ * asynchronous DMA queued on hip_stream (a hipStream_t; NULL = the context's stream): the call returns without waiting for the copy, and
+ * anything queued on hip_stream afterwards sees the record. */
+int vsp_msm_finish_jacobian_device(vsp_ctx *ctx, unsigned slot, void *d_out_jacobian, void *hip_stream);
 
 /* Fold `count` Jacobian records (host, canonical) into one affine point; group: 1 = G1, 2 = G2. */
 int vsp_fold_jacobian(vsp_ctx *ctx, int group, const uint64_t *records, size_t count,
                       uint64_t *out_affine, int *out_is_inf);
+/* Same over records in DEVICE memory (the all-gather's output): copied to a pinned buffer behind whatever hip_stream (NULL = the
+ * context's stream) already holds, that stream is waited for, the fold runs on the host.  count <= 4096. */
+int vsp_fold_jacobian_device(vsp_ctx *ctx, int group, const void *d_records, size_t count, void *hip_stream,
+                             uint64_t *out_affine, int *out_is_inf);
 
 /* ---- evaluation_domain<Fr> (a6): basic radix-2 domain of size m = 2^log_m ------------------
  * In-place on n = 2^log_m canonical Fr values.
@@ -271,7 +293,8 @@ int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d
  * Lets the tests check the kernels' Montgomery arithmetic directly against known-answer vectors. */
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 
-/* ---- wire format helpers (host only, tiny) --------------------------------------------------- */
+/* ---- wire format helpers (host only, tiny) ---------------------------------------------------
+ * compress: VSP_ERR_ARG for a null pointer or a coordinate that is not canonical (>= p). */
 int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]);
 int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]);
 /* Inverse: ZCash-compressed bytes -> canonical affine limbs (the 192-byte proof of bin/cli/src/data.bin[0:192] is A (48) | B (96) |
@@ -281,6 +304,11 @@ int vsp_g1_decompress(const uint8_t in[48], int check_subgroup, uint64_t out_aff
 int vsp_g2_decompress(const uint8_t in[96], int check_subgroup, uint64_t out_affine[24], int *out_is_inf);
 
 /* ---- wire formats of the reference's marshaling_policy (common.hpp:168-203 option::big_endian) --------------------
+ * PROVISIONAL where marked: the marshalling sources are absent submodules, and only the proof bytes, the scalar vectors and the head of
+ * the verification key (4 bytes, the GT element, three points) are pinned by files of the reference.  The tail of the verification key
+ * (vsp_vk_*: count + gamma_ABC_g1 + gamma_g1 and the roles of the three points), the ciphertext vector (vsp_g1_vector_*) and the whole
+ * "fast" proving-key layout (vsp_pk_to_blob / vsp_pk_from_blob) are this library's stated guesses: they round-trip with themselves, a
+ * blob written by the real upstream cli will most likely be refused.  They stay provisional until a reference-produced blob exists.
  * The marshalling sources are absent submodules; csrc/wire.hip lists, field by field, what the reference's own files pin
  * (proof bytes and the head of the extended verification key: bin/cli/src/data.bin; 8-byte counts and 32-byte scalars:
  * protocol_exec.ipynb) and what is a stated guess.  All host-only except the proving-key pair.
@@ -307,7 +335,10 @@ int vsp_vk_from_blob(const uint8_t *blob, size_t len, int check_subgroup, uint32
                      uint64_t delta_g1[12], uint64_t *gamma_abc_g1, size_t capacity, size_t *n_abc, uint64_t gamma_g1[12]);
 /* Proving key: the reference deserialises it inside its timed vote phase (common.hpp:1002-1004; main.cpp:446-456).  vsp_pk_from_blob copies
  * the raw bytes to the GPU once and converts them there (byte order, infinity flags, curve check, Montgomery form, 28-bit-limb table,
- * optionally the window multiples); the result is a resident key (vsp_keypair_pk) without gamma_ABC_g1. */
+ * optionally the window multiples); the result is a resident key (vsp_keypair_pk) without gamma_ABC_g1.  precompute is the bit mask of
+ * vsp_groth16_generate (bit 0 = A, both halves of B, L; H stays plain; bits 1..5 one query each).  Records must be well-formed ZCash
+ * uncompressed records (no compression or sign flag, an infinity record all zero otherwise), on the curve; queries that keep the plain
+ * layout go through the subgroup policy of "bases_check_subgroup".  PROVISIONAL layout (see above). */
 size_t vsp_pk_blob_size(const vsp_keypair *kp);
 int vsp_pk_to_blob(vsp_ctx *ctx, const vsp_keypair *kp, uint8_t *out);
 vsp_keypair *vsp_pk_from_blob(vsp_ctx *ctx, const uint8_t *blob, size_t len, int precompute);

@@ -38,31 +38,47 @@ def test_device_dot_product_mod_r_matches_big_ints():
 
 
 def test_run_sharded_keeps_depth_in_flight_and_folds_every_step():
-    """the timed loop of bench.py: at most `depth` multi-exponentiations in flight, every step's record goes through exchange begin / end
-    exactly once and in order, the exchange of step k ends only after step k + 1's record exists, the last fold is what is returned"""
+    """the timed loop (vote_saver_protocol_amd.sharded.ShardedMsm.run, driven by bench.run_sharded): at most `depth` multi-exponentiations
+    in flight, every step's record goes through exchange begin / end exactly once and in order, the exchange of step k ends only after
+    step k + 1's record exists, the last fold is what is returned"""
     for depth in (1, 2, 3, 4):
         for steps in (1, 2, 3, 7):
             log = []
 
             class Bases:
+                group = 1
                 def __init__(self): self.in_flight = 0; self.count = 0
-                def msm_launch(self, slot, d_s): self.in_flight += 1; assert self.in_flight <= depth - 1 + 1; log.append(("launch", slot))
+                def msm_launch(self, slot, d_s): self.in_flight += 1; assert self.in_flight <= depth; log.append(("launch", slot))
                 def msm_finish_jacobian(self, slot): self.in_flight -= 1; self.count += 1; log.append(("finish", slot)); return np.array([self.count])
-                def msm_jacobian(self, d_s): self.count += 1; log.append(("blocking",)); return np.array([self.count])
 
             class Problem:
                 pass
             prob = Problem(); prob.bases = Bases(); prob.d_s = None; prob.group = 1
             begun, ended = [], []
 
-            def begin(rec, group, buf):
-                begun.append(int(rec[0])); assert buf == (len(begun) - 1) & 1
-                return int(rec[0])
+            class Exchange:
+                def begin(self, bases, slot, buf):
+                    rec = bases.msm_finish_jacobian(slot)
+                    begun.append(int(rec[0])); assert buf == (len(begun) - 1) & 1
+                    return int(rec[0])
 
-            def end(h):
-                ended.append(h); assert len(begun) >= min(h + 1, steps)      # step h's exchange ends after step h + 1 has begun (or at the very end)
-                return ("folded", h)
+                def end(self, h):
+                    ended.append(h); assert len(begun) >= min(h + 1, steps)      # step h's exchange ends after step h + 1 has begun (or at the very end)
+                    return ("folded", h)
 
-            el, res = bench.run_sharded(prob, steps, 0, (begin, end), lambda: None, depth)
+            el, res = bench.run_sharded(prob, steps, 0, Exchange(), lambda: None, depth)
             assert begun == list(range(1, steps + 1)) and ended == begun and res == ("folded", steps) and el >= 0
             assert prob.bases.in_flight == 0
+            slots = {x[1] for x in log if x[0] == "launch"}
+            assert len(slots) <= depth and (slots == {0} if depth == 1 else 0 not in slots)      # one in flight: the context's stream; else the slots' own
+
+
+def test_launcher_refuses_cleanly_without_gpus_and_never_imports_torch_first():
+    """`python bench.py --gpus N` as a plain process: the parent counts GPUs from the KFD topology (no HIP call) and, on a box with fewer
+    GPUs than ranks, returns 3 without starting anything"""
+    import subprocess, sys
+    if bench.visible_gpu_count() not in (0, None):
+        import pytest
+        pytest.skip("GPUs present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and r.stdout == "" and "nothing was launched" in r.stderr

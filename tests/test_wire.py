@@ -123,6 +123,15 @@ def test_proving_key_blob_round_trip_on_the_gpu(ctx, cref):
     b2 = bytearray(blob); b2[off_a] |= 0x80                                         # claims compressed form
     with pytest.raises(v.VspError, match="uncompressed"):
         v.Keypair.from_blob(ctx, bytes(b2))
+    b2 = bytearray(blob); b2[off_a] |= 0x20                                         # the sign flag exists only in the compressed form
+    with pytest.raises(v.VspError, match="uncompressed"):
+        v.Keypair.from_blob(ctx, bytes(b2))
+    inf_at = next(i for i, p in enumerate(P1("B_query_g1")) if p is None)           # an infinity record (G1 half of a B_query pair) with a payload
+    off_b = 672 + 8 + 96 * len(P1("A_query")) + 8 + 288 * inf_at + 192
+    assert blob[off_b] == 0x40
+    b2 = bytearray(blob); b2[off_b + 50] = 1
+    with pytest.raises(v.VspError, match="uncompressed"):
+        v.Keypair.from_blob(ctx, bytes(b2))
     b3 = bytearray(blob); b3[off_a + 96 + 95] ^= 1                                  # y of the second point off by one
     with pytest.raises(v.VspError, match="curve"):
         v.Keypair.from_blob(ctx, bytes(b3))

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "vsp_msm_launch": (_I, [_P, _U, _P, _SZ, _SZ, _P]),
     "vsp_msm_finish_jacobian": (_I, [_P, _U, _P]),
     "vsp_fold_jacobian": (_I, [_P, _I, _P, _SZ, _P, _P]),
+    "vsp_msm_finish_jacobian_device": (_I, [_P, _U, _P, _P]),
+    "vsp_fold_jacobian_device": (_I, [_P, _I, _P, _SZ, _P, _P, _P]),
     "vsp_ntt_fr": (_I, [_P, _P, _U, _I, _P]),
     "vsp_ntt_fr_device": (_I, [_P, _P, _U, _I, _P]),
     "vsp_witness_map_h": (_I, [_P, _P, _P, _P, _U, _P]),

@@ -172,6 +172,11 @@ class Bases:
         self.ctx.check(self.ctx.lib.vsp_msm_finish_jacobian(self.ctx.h, slot, _ptr(out)))
         return out
 
+    def msm_finish_jacobian_device(self, slot, d_out, stream=None):
+        """Same, the record left in DEVICE memory at d_out (pointer / torch tensor) by an asynchronous copy queued on `stream`
+        (a hipStream_t handle; None = the context's stream) -- where the RCCL all-gather of the sharded MSM reads it."""
+        self.ctx.check(self.ctx.lib.vsp_msm_finish_jacobian_device(self.ctx.h, slot, _ptr(d_out), C.c_void_p(stream) if stream else None))
+
     def msm_jacobian(self, d_scalars, n=None, first=0):
         """Same, result as the Jacobian partial-sum record (18 / 36 uint64) ranks exchange."""
         n = self.n - first if n is None else n
@@ -208,6 +213,14 @@ def fold_jacobian(ctx, records, group=1):
     out = np.zeros(12 if group == 1 else 24, np.uint64)
     inf = C.c_int(0)
     ctx.check(ctx.lib.vsp_fold_jacobian(ctx.h, group, _ptr(records), records.shape[0], _ptr(out), C.byref(inf)))
+    return out
+
+
+def fold_jacobian_device(ctx, d_records, count, group=1, stream=None):
+    """Fold `count` records that sit in device memory (the all-gather's output) behind the work already queued on `stream`."""
+    out = np.zeros(12 if group == 1 else 24, np.uint64)
+    inf = C.c_int(0)
+    ctx.check(ctx.lib.vsp_fold_jacobian_device(ctx.h, group, _ptr(d_records), count, C.c_void_p(stream) if stream else None, _ptr(out), C.byref(inf)))
     return out
 
 
@@ -465,8 +478,13 @@ class SaverPublicKey:
 
     def __init__(self, ctx, pk_words, gamma_abc_g1, msg_size):
         self.ctx, self.n = ctx, int(msg_size)
-        self.words = _u64(pk_words)
+        self.words = _u64(pk_words).reshape(-1)
         gabc = _u64(gamma_abc_g1, 12)
+        # the C side reads vsp_saver_pk_words(n) words and n + 1 accumulation elements unconditionally (the C ABI carries no lengths)
+        if self.n < 1 or self.words.shape[0] != ctx.lib.vsp_saver_pk_words(self.n):
+            raise ValueError("SaverPublicKey: the flat public key must have vsp_saver_pk_words(msg_size) words")
+        if gabc.shape[0] < self.n + 1:
+            raise ValueError("SaverPublicKey: the verification key has fewer than msg_size + 1 accumulation elements")
         self.h = ctx.lib.vsp_saver_pk_load(ctx.h, self.n, _ptr(self.words), _ptr(gabc))
         if not self.h:
             raise VspError("saver_pk_load failed: " + ctx.last_error())
@@ -494,6 +512,8 @@ def saver_rerandomize(ctx, spk, delta_g2, rnd3, ct, proof_abc):
     """rerandomize<elgamal_verifiable>(rnd[3], ct, {pk_eid, gg_keypair, proof}) (common.hpp:1138-1145), rnd3 = (r', z1, z2)."""
     ct = _u64(ct, 12).copy()
     A, B, Cc = (_u64(x).copy() for x in proof_abc)
+    if ct.shape[0] != spk.n + 2 or A.size != 12 or B.size != 24 or Cc.size != 12 or _u64(delta_g2).size != 24 or _u64(rnd3).size != 12:
+        raise ValueError("rerandomize: ciphertext of msg_size + 2 points, proof (A[12], B[24], C[12]), delta_g2[24] and three random scalars expected")
     proof = np.zeros(192, np.uint8)
     ctx.check(ctx.lib.vsp_saver_rerandomize(ctx.h, spk.h, _ptr(_u64(delta_g2)), _ptr(_u64(rnd3).reshape(12)), _ptr(ct), _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
     return ct, (A, B, Cc), proof.tobytes()
@@ -509,11 +529,17 @@ def fixed_base_mul(ctx, d_scalars, n, group=1):
 
 
 def g1_compress(affine):
-    out = np.zeros(48, np.uint8); _lib.load().vsp_g1_compress(_ptr(_u64(affine)), _ptr(out)); return out.tobytes()
+    out = np.zeros(48, np.uint8)
+    if _lib.load().vsp_g1_compress(_ptr(_u64(affine).reshape(12)), _ptr(out)) != 0:
+        raise ValueError("g1_compress: a coordinate is not canonical (>= p)")
+    return out.tobytes()
 
 
 def g2_compress(affine):
-    out = np.zeros(96, np.uint8); _lib.load().vsp_g2_compress(_ptr(_u64(affine)), _ptr(out)); return out.tobytes()
+    out = np.zeros(96, np.uint8)
+    if _lib.load().vsp_g2_compress(_ptr(_u64(affine).reshape(24)), _ptr(out)) != 0:
+        raise ValueError("g2_compress: a coordinate is not canonical (>= p)")
+    return out.tobytes()
 
 
 def g1_decompress(data, check_subgroup=True):

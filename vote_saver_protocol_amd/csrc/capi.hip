@@ -138,6 +138,7 @@ void vsp_destroy(vsp_ctx *ctx) {
                       &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
     for (DevBuf *b : bufs) free_buf(*b);
     msm_free_slots(ctx);
+    if (ctx->h_fold) hipHostFree(ctx->h_fold);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1); hipEventDestroy(ctx->ev_aux);
     for (hipStream_t ps : ctx->prove_streams) if (ps) hipStreamDestroy(ps);
     hipStreamDestroy(ctx->own_stream);
@@ -210,76 +211,107 @@ int vsp_host_unregister(vsp_ctx *ctx, void *ptr) {
 
 // ---- bases ------------------------------------------------------------------------------------
 }  // extern "C"
-// Known-answer check of the 28-bit-limb accumulation THROUGH k_accum28 itself (its products are hand-laid-out routines entered
-// with a private calling convention, which the compiler's hazard recogniser and register allocator cannot see into; field-level
-// selftests run them in another code arrangement).  Once per context and group, at the first table built: the same
-// multi-exponentiation over the first points of the new bases runs through k_accum28 and through the generic 12 x 32-bit k_accum;
-// the two affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0):
-// every later multi-exponentiation takes the generic kernel.  Returns true when the table may be used.
-static bool fp28_known_answer_check(vsp_ctx *ctx, const vsp_bases *b, const void *t28, size_t count, bool glv) {
-    const int gi = b->group - 1;
+// Known-answer check of the hand-laid-out field routines THROUGH the kernels that use them (their products are entered with a private
+// calling convention the compiler's hazard recogniser and register allocator cannot see into; field-level selftests run them in another
+// code arrangement).  Once per context and group, before the first 28-bit table is used, over points the LIBRARY generates (4096
+// multiples of the generator: in the subgroup by construction, independent of whatever the caller uploads): the same multi-exponentiation
+//   (a) through k_accum28 over the endomorphism layout, the 28-bit merges (k_merge_a, k_merge2: its scalars hold zeros and ones, so one
+//       bucket is split in tens of parts), k_dimsum and k_dimbits / k_dimweight -- the default plan;
+//   (b) the same with short bucket parts forced ("msm_split" = 6: every bucket is cut in several parts, the merges' full additions run
+//       thousands of times) and the other last step of the bucket reduction;
+//   (c) through the generic 12 x 32-bit kernels, no split.
+// All three affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0:
+// every later multi-exponentiation takes the generic kernels).  Returns true when 28-bit tables may be used.
+static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
+    const int gi = group - 1;
     if (ctx->fp28_checked[gi] != 0) return ctx->fp28_checked[gi] > 0;
     if (ctx->msm_work[0].active) return true;                 // slot 0 busy (unusual): check at the next table instead
-    const size_t n = count < 4096 ? count : 4096;
-    std::vector<uint64_t> sc(n * 4);
-    uint64_t x = 0x9E3779B97F4A7C15ULL ^ (uint64_t)b->group;
+    const size_t n = 4096;
+    std::vector<uint64_t> sc(2 * n * 4);                      // [0, n): the multiples that make the points; [n, 2n): the scalars of the check
+    uint64_t x = 0x9E3779B97F4A7C15ULL ^ (uint64_t)group;
     auto next = [&]() { x += 0x9E3779B97F4A7C15ULL; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = 0; i < 2 * n; i++) {
         sc[4 * i] = next(); sc[4 * i + 1] = next(); sc[4 * i + 2] = next(); sc[4 * i + 3] = next() >> 2;     // < 2^254 < r
-        if (i % 7 == 3) { sc[4 * i] &= 1; sc[4 * i + 1] = sc[4 * i + 2] = sc[4 * i + 3] = 0; }               // zeros and ones among them
+        if (i >= n && i % 7 == 3) { sc[4 * i] &= 1; sc[4 * i + 1] = sc[4 * i + 2] = sc[4 * i + 3] = 0; }     // zeros and ones among the check's scalars
     }
-    bool same = false;
-    if (ensure(ctx, ctx->msm_scalars, n * 32) == VSP_OK &&
-        hipMemcpyAsync(ctx->msm_scalars.p, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-        hipStreamSynchronize(ctx->stream) == hipSuccess) {
-        const Fr *ds = (const Fr *)ctx->msm_scalars.p;
-        if (b->group == 1) {
-            XYZZ<HFp> r28, rgen;
-            if (msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28, glv) == VSP_OK && msm_g1_finish(ctx, 0, &r28) == VSP_OK &&
-                msm_g1_launch(ctx, 0, (const G1Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g1_finish(ctx, 0, &rgen) == VSP_OK) {
-                Affine<HFp> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
-                same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
-            }
-        } else {
-            XYZZ<HFp2> r28, rgen;
-            if (msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, t28, glv) == VSP_OK && msm_g2_finish(ctx, 0, &r28) == VSP_OK &&
-                msm_g2_launch(ctx, 0, (const G2Affine *)b->d, ds, n, VSP_MSM_DENSE, nullptr, nullptr) == VSP_OK && msm_g2_finish(ctx, 0, &rgen) == VSP_OK) {
-                Affine<HFp2> a = xyzz_to_affine(r28), c = xyzz_to_affine(rgen);
-                same = is_inf(r28) == is_inf(rgen) && eq(a.x, c.x) && eq(a.y, c.y);
-            }
+    const size_t esz = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine), row = group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
+    void *d_pts = nullptr, *t28 = nullptr;
+    bool same = false, ran = false;
+    const long saved_split = ctx->opts.count("msm_split") ? ctx->opts["msm_split"] : 0, saved_db = ctx->opts.count("msm_dimbits") ? ctx->opts["msm_dimbits"] : -1;
+    if (ensure(ctx, ctx->msm_scalars, 2 * n * 32) == VSP_OK && ensure(ctx, ctx->val_flag, 16) == VSP_OK &&
+        hipMemcpyAsync(ctx->msm_scalars.p, sc.data(), 2 * n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess && hipMalloc(&d_pts, n * esz) == hipSuccess && hipMalloc(&t28, 2 * n * row) == hipSuccess) {
+        const Fr *dk = (const Fr *)ctx->msm_scalars.p, *ds = dk + n;
+        int rc = group == 1 ? fixed_base_mul_g1(ctx, dk, n, d_pts) : fixed_base_mul_g2(ctx, dk, n, d_pts);
+        if (rc == VSP_OK) rc = group == 1 ? bases_to_mont_g1(ctx, d_pts, (G1Affine *)d_pts, n, 0, (uint32_t *)ctx->val_flag.p)
+                                          : bases_to_mont_g2(ctx, d_pts, (G2Affine *)d_pts, n, 0, (uint32_t *)ctx->val_flag.p);
+        if (rc == VSP_OK) rc = group == 1 ? msm_g1_table28(ctx, (const G1Affine *)d_pts, n, t28, true) : msm_g2_table28(ctx, (const G2Affine *)d_pts, n, t28, true);
+        if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
+            ran = true;
+            auto run = [&](const void *table, bool glv, long split, long dimbits, uint64_t *aff, int *inf) -> bool {
+                if (split) ctx->opts["msm_split"] = split; else ctx->opts.erase("msm_split");
+                if (dimbits >= 0) ctx->opts["msm_dimbits"] = dimbits; else ctx->opts.erase("msm_dimbits");
+                if (group == 1) {
+                    XYZZ<HFp> r;
+                    if (msm_g1_launch(ctx, 0, (const G1Affine *)d_pts, ds, n, VSP_MSM_DENSE, nullptr, table, glv) != VSP_OK || msm_g1_finish(ctx, 0, &r) != VSP_OK) return false;
+                    Affine<HFp> a = xyzz_to_affine(r); host_store_g1(aff, a); *inf = is_inf(r);
+                } else {
+                    XYZZ<HFp2> r;
+                    if (msm_g2_launch(ctx, 0, (const G2Affine *)d_pts, ds, n, VSP_MSM_DENSE, nullptr, table, glv) != VSP_OK || msm_g2_finish(ctx, 0, &r) != VSP_OK) return false;
+                    Affine<HFp2> a = xyzz_to_affine(r); host_store_g2(aff, a); *inf = is_inf(r);
+                }
+                return true;
+            };
+            uint64_t ra[24], rb[24], rc3[24]; int ia = 0, ib = 0, ic = 0;
+            memset(ra, 0, sizeof ra); memset(rb, 0, sizeof rb); memset(rc3, 0, sizeof rc3);
+            const bool okr = run(t28, true, 0, -1, ra, &ia) && run(t28, true, 6, group == 1 ? 0 : 1, rb, &ib) && run(nullptr, false, 0, -1, rc3, &ic);
+            same = okr && ia == ic && ib == ic && !ic && memcmp(ra, rc3, sizeof ra) == 0 && memcmp(rb, rc3, sizeof rb) == 0;
         }
     }
+    if (saved_split) ctx->opts["msm_split"] = saved_split; else ctx->opts.erase("msm_split");
+    if (saved_db >= 0) ctx->opts["msm_dimbits"] = saved_db; else ctx->opts.erase("msm_dimbits");
+    if (d_pts) hipFree(d_pts);
+    if (t28) hipFree(t28);
+    hipGetLastError();
+    if (!ran) { ctx->stats[group == 1 ? "msm_fp28_selfcheck_g1" : "msm_fp28_selfcheck_g2"] = 0.0; return false; }      // could not run (out of memory): no verdict, no 28-bit table this time
     { auto it = ctx->opts.find("msm_fp28_selfcheck_fault"); if (it != ctx->opts.end() && it->second) same = false; }   // test hook: exercise the fallback
     ctx->fp28_checked[gi] = same ? 1 : -1;
-    ctx->stats[b->group == 1 ? "msm_fp28_selfcheck_g1" : "msm_fp28_selfcheck_g2"] = same ? 1.0 : -1.0;
-    if (!same) { ctx->opts["msm_fp28"] = 0; ctx->err = "msm: the 28-bit-limb accumulation kernel failed its known-answer check; generic kernel in use"; }
+    ctx->stats[group == 1 ? "msm_fp28_selfcheck_g1" : "msm_fp28_selfcheck_g2"] = same ? 1.0 : -1.0;
+    if (!same) { ctx->opts["msm_fp28"] = 0; ctx->err = "msm: the 28-bit-limb kernels failed their known-answer check; generic kernels in use"; }
     return same;
 }
 // the points once more on 14 x 28-bit limbs for the accumulation kernel (fp28.h); option "msm_fp28" = 0 switches it off.
-// Plain bases (no window multiples) get the endomorphism layout: 2 count rows, (P_i, phi(P_i)) interleaved (option "msm_glv" = 0: off)
-static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
-    if (b->d28) { hipFree(b->d28); b->d28 = nullptr; }
-    b->glv = false;
+// Plain bases (no window multiples) whose points are known to satisfy phi(P) = lambda P (vsp_bases.in_subgroup) get the endomorphism
+// layout: 2 count rows, (P_i, phi(P_i)) interleaved (option "msm_glv" = 0: off; 2: on for any size and WITHOUT the check -- the caller vouches)
+static bool glv_wanted(vsp_ctx *ctx, int group, size_t count, unsigned pre_c) {
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
     long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
-    const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
+    const size_t row = group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
     // The split halves the bucket sets (and the host Horner chain) but doubles the table and the sort's input.  Measured
     // (tools/msm_sizes.py, bench.py; one in flight / three in flight, ms): G1 2^16 1.49 / 1.42 -> 1.35 / 0.80, G1 2^18 2.31 / 1.29 ->
     // 2.04 / 1.27, G1 2^20 4.24 / 3.35 -> 3.98 / 3.34, a 2^20-constraint proof 8.71 -> 8.45 ms (plain key: 9.98 -> 8.95);
     // G2 2^16 3.01 / 1.58 -> 2.67 / 1.40, G2 2^18 5.21 / 3.21 -> 5.56 / 2.90, G2 2^19 7.23 / 4.82 -> 8.28 / 5.58 (dense scalars:
     // the lane-pair merges of the split buckets cost more than the windows saved).  So: on while the doubled table is at most
     // 256 MB for G1 (2^20 points) and 128 MB for G2 (2^18 points); "msm_glv" = 2 forces it on, 0 switches it off.
-    const size_t glv_limit = b->group == 1 ? ((size_t)256 << 20) : ((size_t)128 << 20);
-    const bool glv = want_glv && b->pre_c == 0 && count < ((size_t)1 << 30) && (want_glv >= 2 || 2 * count * row <= glv_limit);
+    const size_t glv_limit = group == 1 ? ((size_t)256 << 20) : ((size_t)128 << 20);
+    return want && want_glv && pre_c == 0 && count >= 1024 && count < ((size_t)1 << 30) && (want_glv >= 2 || 2 * count * row <= glv_limit);
+}
+static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
+    if (b->d28) { hipFree(b->d28); b->d28 = nullptr; }
+    b->glv = false;
+    long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
+    long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
+    if (!want || !fp28_known_answer_check(ctx, b->group)) return;                 // the check may have just switched "msm_fp28" off
+    const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
+    const bool glv = glv_wanted(ctx, b->group, count, b->pre_c) && (b->in_subgroup > 0 || want_glv >= 2);
     void *t28 = nullptr;
-    if (!want || hipMalloc(&t28, count * row * (glv ? 2 : 1)) != hipSuccess) { hipGetLastError(); return; }
+    if (hipMalloc(&t28, count * row * (glv ? 2 : 1)) != hipSuccess) { hipGetLastError(); return; }
     int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28, glv) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28, glv);
-    // the known-answer check runs over plain points: a table of window multiples is checked through its first slice, read as plain bases
-    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess && fp28_known_answer_check(ctx, b, t28, b->n < count ? b->n : count, glv)) { b->d28 = t28; b->glv = glv; }
+    if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) { b->d28 = t28; b->glv = glv; }
     else { hipFree(t28); hipGetLastError(); }
 }
-extern "C" {
-static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n) {
+namespace vsp {
+vsp_bases *bases_create(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n, int trust) {
     if (!ctx) return nullptr;
     if (!src && n) { set_error(ctx, VSP_ERR_ARG, "bases: null pointer"); return nullptr; }
     hipSetDevice(ctx->device);
@@ -295,25 +327,46 @@ static vsp_bases *bases_new(vsp_ctx *ctx, int group, const void *src, bool src_o
         }
         // boundary validation (include/vsp.h): coordinates below p always; the curve equation unless option "bases_check_curve" = 0
         long check_curve = 1; { auto it = ctx->opts.find("bases_check_curve"); if (it != ctx->opts.end()) check_curve = it->second; }
+        // the subgroup (option "bases_check_subgroup"): 1 (default) = checked where the endomorphism split would be used -- bases that fail
+        // keep the plain layout, whose result is exact for ANY curve point (like the reference's generic multiexp); 2 = always checked, a
+        // failing upload is refused; 0 = never checked, and then never split unless "msm_glv" = 2 (the caller vouches for the points)
+        long check_sub = 1; { auto it = ctx->opts.find("bases_check_subgroup"); if (it != ctx->opts.end()) check_sub = it->second; }
         uint32_t h_flag = 0;
         rc = ensure(ctx, ctx->val_flag, 16);
         if (rc == VSP_OK && hipMemsetAsync(ctx->val_flag.p, 0, 16, ctx->stream) != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "bases: memset failed");
         if (rc == VSP_OK)
             rc = group == 1 ? bases_to_mont_g1(ctx, src, (G1Affine *)b->d, n, (int)check_curve, (uint32_t *)ctx->val_flag.p)
                             : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n, (int)check_curve, (uint32_t *)ctx->val_flag.p);
+        bool sub_checked = false;
+        if (trust == BASES_OWN) b->in_subgroup = 1;
+        else if (rc == VSP_OK && trust == BASES_CALLER && check_curve && (check_sub >= 2 || (check_sub == 1 && glv_wanted(ctx, group, n, 0)))) {
+            rc = group == 1 ? subgroup_check_g1(ctx, (const G1Affine *)b->d, n, (uint32_t *)ctx->val_flag.p)
+                            : subgroup_check_g2(ctx, (const G2Affine *)b->d, n, (uint32_t *)ctx->val_flag.p);
+            sub_checked = true;
+        }
         if (rc == VSP_OK && (hipMemcpyAsync(&h_flag, ctx->val_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                              hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = set_error(ctx, VSP_ERR_HIP, "bases: conversion failed");
-        if (rc == VSP_OK && h_flag)
+        if (rc == VSP_OK && (h_flag & 3u))
             rc = set_error(ctx, VSP_ERR_ARG, (h_flag & 1u) ? "bases: a coordinate is not canonical (>= p)" : "bases: a point is not on the curve");
+        if (rc == VSP_OK && sub_checked) {
+            ctx->stats["bases_subgroup_checks"] += 1;
+            b->in_subgroup = (h_flag & 4u) ? -1 : 1;
+            if (h_flag & 4u) {
+                ctx->stats["bases_outside_subgroup"] += 1;
+                if (check_sub >= 2) rc = set_error(ctx, VSP_ERR_ARG, "bases: a point is not in the order-r subgroup");
+            }
+        }
         if (rc != VSP_OK) { hipFree(b->d); delete b; return nullptr; }
         if (n >= 1024) build_table28(ctx, b, n);       // best effort: without it the 12 x 32-bit kernel runs
     }
     return b;
 }
-vsp_bases *vsp_bases_upload_g1(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_new(ctx, 1, bases, false, n); }
-vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_new(ctx, 2, bases, false, n); }
-vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_new(ctx, 1, d_bases, true, n); }
-vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_new(ctx, 2, d_bases, true, n); }
+}  // namespace vsp
+extern "C" {
+vsp_bases *vsp_bases_upload_g1(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_create(ctx, 1, bases, false, n, BASES_CALLER); }
+vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases, size_t n) { return bases_create(ctx, 2, bases, false, n, BASES_CALLER); }
+vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_create(ctx, 1, d_bases, true, n, BASES_CALLER); }
+vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_create(ctx, 2, d_bases, true, n, BASES_CALLER); }
 size_t vsp_bases_count(const vsp_bases *b) { return b ? b->n : 0; }
 void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
     if (!b) return;
@@ -411,20 +464,48 @@ int vsp_msm_launch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t f
     VSP_HIP(hipSetDevice(ctx->device));
     return launch_on_bases(ctx, slot, bases, first, n, (const Fr *)d_scalars, -1);
 }
-int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian) {
-    if (!ctx) return VSP_ERR_ARG;
-    if (slot >= VSP_MSM_SLOTS || !out_jacobian) return set_error(ctx, VSP_ERR_ARG, "msm: bad slot or null output");
+// the Jacobian record of a finished slot (18 / 36 canonical words); returns the words written
+static int finish_record(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian, size_t *words) {
     if (ctx->slot_group[slot] == 1) {
         XYZZ<HFp> a; VSP_TRY(msm_g1_finish(ctx, slot, &a));
         Jacobian<HFp> j = xyzz_to_jacobian(a);
         host_store_canon(out_jacobian, j.X); host_store_canon(out_jacobian + 6, j.Y); host_store_canon(out_jacobian + 12, j.Z);
+        *words = 18;
     } else {
         XYZZ<HFp2> a; VSP_TRY(msm_g2_finish(ctx, slot, &a));
         Jacobian<HFp2> j = xyzz_to_jacobian(a);
         host_store_canon(out_jacobian, j.X.c0); host_store_canon(out_jacobian + 6, j.X.c1);
         host_store_canon(out_jacobian + 12, j.Y.c0); host_store_canon(out_jacobian + 18, j.Y.c1);
         host_store_canon(out_jacobian + 24, j.Z.c0); host_store_canon(out_jacobian + 30, j.Z.c1);
+        *words = 36;
     }
+    return VSP_OK;
+}
+int vsp_msm_finish_jacobian(vsp_ctx *ctx, unsigned slot, uint64_t *out_jacobian) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (slot >= VSP_MSM_SLOTS || !out_jacobian) return set_error(ctx, VSP_ERR_ARG, "msm: bad slot or null output");
+    size_t words = 0;
+    return finish_record(ctx, slot, out_jacobian, &words);
+}
+// The exchange step of the sharded multi-exponentiation wants the record in DEVICE memory (the RCCL all-gather reads it there).  The
+// last step of a multi-exponentiation is a chain of c * W dependent doublings, which the host runs ~50x faster than a GPU lane
+// (DESIGN.md 3.4), so the record is born on the host: it is written into a pinned ring entry of the slot and copied to d_out_jacobian
+// by an asynchronous DMA queued on hip_stream (NULL = the context's stream) -- the caller's host thread never waits for the copy, and
+// work queued on hip_stream afterwards (the all-gather) sees the record.
+int vsp_msm_finish_jacobian_device(vsp_ctx *ctx, unsigned slot, void *d_out_jacobian, void *hip_stream) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (slot >= VSP_MSM_SLOTS || !d_out_jacobian) return set_error(ctx, VSP_ERR_ARG, "msm: bad slot or null output");
+    VSP_HIP(hipSetDevice(ctx->device));
+    MsmWork &wk = ctx->msm_work[slot];
+    if (!wk.inited || !wk.h_rec) return set_error(ctx, VSP_ERR_ARG, "msm: finish without launch");
+    const unsigned k = wk.rec_idx++ % MsmWork::REC_RING;
+    VSP_HIP(hipEventSynchronize(wk.rec_ev[k]));                 // the copy that last read this ring entry (long done in practice; never-recorded events return at once)
+    uint64_t *rec = (uint64_t *)((char *)wk.h_rec + (size_t)k * 288);
+    size_t words = 0;
+    VSP_TRY(finish_record(ctx, slot, rec, &words));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    VSP_HIP(hipMemcpyAsync(d_out_jacobian, rec, words * 8, hipMemcpyHostToDevice, st));
+    VSP_HIP(hipEventRecord(wk.rec_ev[k], st));
     return VSP_OK;
 }
 
@@ -453,12 +534,36 @@ int vsp_fold_jacobian(vsp_ctx *ctx, int group, const uint64_t *records, size_t c
     return set_error(ctx, VSP_ERR_ARG, "fold: group must be 1 or 2");
 }
 
+// Fold records that sit in DEVICE memory (the output of the all-gather): one asynchronous copy of count * 144 / 288 bytes into a pinned
+// buffer on hip_stream (NULL = the context's stream) -- behind whatever produced the records on that stream --, a wait for that stream,
+// then the host fold.  The result is wanted on the host (the prover's caller assembles the proof there).
+int vsp_fold_jacobian_device(vsp_ctx *ctx, int group, const void *d_records, size_t count, void *hip_stream, uint64_t *out_affine, int *out_is_inf) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (group != 1 && group != 2) return set_error(ctx, VSP_ERR_ARG, "fold: group must be 1 or 2");
+    if (!d_records && count) return set_error(ctx, VSP_ERR_ARG, "fold: null records");
+    if (count > 4096) return set_error(ctx, VSP_ERR_ARG, "fold: more than 4096 records");
+    VSP_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = count * (size_t)(group == 1 ? 144 : 288);
+    if (bytes > ctx->h_fold_cap) {
+        if (ctx->h_fold) { hipHostFree(ctx->h_fold); ctx->h_fold = nullptr; ctx->h_fold_cap = 0; }
+        const size_t want = bytes < 8192 ? 8192 : bytes;
+        VSP_HIP(hipHostMalloc(&ctx->h_fold, want, hipHostMallocDefault));
+        ctx->h_fold_cap = want;
+    }
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (bytes) {
+        VSP_HIP(hipMemcpyAsync(ctx->h_fold, d_records, bytes, hipMemcpyDeviceToHost, st));
+        VSP_HIP(hipStreamSynchronize(st));
+    }
+    return vsp_fold_jacobian(ctx, group, (const uint64_t *)ctx->h_fold, count, out_affine, out_is_inf);
+}
+
 static int msm_host(vsp_ctx *ctx, int group, const uint64_t *bases, const uint64_t *scalars, size_t n, uint64_t *out_affine, int *out_is_inf) {
     if (!ctx) return VSP_ERR_ARG;
     if ((!bases || !scalars) && n) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
     VSP_HIP(hipSetDevice(ctx->device));
-    vsp_bases *b = group == 1 ? vsp_bases_upload_g1(ctx, bases, n) : vsp_bases_upload_g2(ctx, bases, n);
-    if (!b) return VSP_ERR_NOMEM;
+    vsp_bases *b = bases_create(ctx, group, bases, false, n, BASES_TRANSIENT);      // one call's bases: no endomorphism split, hence no subgroup check
+    if (!b) return ctx->err.find("hipMalloc") != std::string::npos ? VSP_ERR_NOMEM : VSP_ERR_ARG;
     int rc = ensure(ctx, ctx->msm_scalars, n * 32);
     if (rc == VSP_OK && n) {
         if (hipMemcpyAsync(ctx->msm_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "msm: H2D of scalars failed");
@@ -633,9 +738,15 @@ int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d
 }
 
 // ---- ZCash compressed encoding (the wire format of reference bin/cli/src/data.bin[0:192]) ----------
+static bool canon_lt_p(const uint64_t *l) {
+    for (int i = 5; i >= 0; i--) { if (l[i] < FpP64::MOD[i]) return true; if (l[i] > FpP64::MOD[i]) return false; }
+    return false;
+}
+// VSP_ERR_ARG for a null pointer or a coordinate that is not canonical (>= p: its top bits would collide with the flag bits)
 int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]) {
     if (!affine || !out) return VSP_ERR_ARG;
     if (limbs_zero(affine, 12)) { memset(out, 0, 48); out[0] = 0xC0; return VSP_OK; }
+    if (!canon_lt_p(affine) || !canon_lt_p(affine + 6)) return VSP_ERR_ARG;
     be48(out, affine);
     out[0] |= 0x80;
     if (fp_lex_larger(affine + 6)) out[0] |= 0x20;
@@ -644,6 +755,7 @@ int vsp_g1_compress(const uint64_t affine[12], uint8_t out[48]) {
 int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]) {
     if (!affine || !out) return VSP_ERR_ARG;
     if (limbs_zero(affine, 24)) { memset(out, 0, 96); out[0] = 0xC0; return VSP_OK; }
+    for (int k = 0; k < 4; k++) if (!canon_lt_p(affine + 6 * k)) return VSP_ERR_ARG;
     be48(out, affine + 6);          // x.c1 first
     be48(out + 48, affine);         // then x.c0
     out[0] |= 0x80;
@@ -657,10 +769,6 @@ int vsp_g2_compress(const uint64_t affine[24], uint8_t out[96]) {
 // ---- decompression (the inverse of the above): x from the big-endian bytes, y = sqrt(x^3 + b) with the sign the flag names ----
 static void from_be48(uint64_t *l, const uint8_t *in) {
     for (int i = 0; i < 6; i++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)in[47 - (i * 8 + b)] << (8 * b); l[i] = v; }
-}
-static bool canon_lt_p(const uint64_t *l) {
-    for (int i = 5; i >= 0; i--) { if (l[i] < FpP64::MOD[i]) return true; if (l[i] > FpP64::MOD[i]) return false; }
-    return false;
 }
 // a^((p+1)/4) -- the square root when a is a quadratic residue (p = 3 mod 4); returns false when it is not
 static bool fp_sqrt(const HFp &a, HFp &out) {

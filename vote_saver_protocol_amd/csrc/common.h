@@ -65,6 +65,10 @@ struct MsmWork {
     DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
     bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
     void *h_pinned = nullptr;
+    // vsp_msm_finish_jacobian_device: the Jacobian record leaves through a small pinned ring (REC_RING entries of 288 bytes) so that the
+    // copy into the caller's device buffer is an asynchronous DMA; rec_ev[k] marks the copy out of entry k as done
+    static constexpr unsigned REC_RING = 4;
+    void *h_rec = nullptr; hipEvent_t rec_ev[REC_RING] = {nullptr, nullptr, nullptr, nullptr}; unsigned rec_idx = 0;
     void *h_census = nullptr;            // pinned: count of scalars that are neither 0 nor 1
     hipEvent_t census_done = nullptr;
     bool census_pending = false; size_t census_n = 0; const void *census_scalars = nullptr;
@@ -97,7 +101,9 @@ struct vsp_ctx {
     int slot_group[vsp::VSP_MSM_SLOTS] = {1, 1, 1, 1, 1, 1};
     bool lds_attr_set[2] = {false, false};
     bool ntt_attr_set = false;
+    int ntt29_checked = 0;              // known-answer check of k_ntt29_pass: 0 not yet, 1 passed, -1 failed (8 x 32-bit kernel in use), 2 running
     vsp::DevBuf msm_scalars;
+    void *h_fold = nullptr; size_t h_fold_cap = 0;      // pinned landing buffer of vsp_fold_jacobian_device (the ranks' records)
     vsp::DevBuf val_flag;               // one word: validation result of the last bases upload
     int fp28_checked[2] = {0, 0};       // known-answer check of the 28-bit-limb accumulation kernels, per group: 0 not yet, 1 passed, -1 failed (kernel disabled)
     // fixed-base tables (generator multiples), built lazily
@@ -112,6 +118,8 @@ struct vsp_bases {
     void *d = nullptr;      // device array of Affine<Fp> / Affine<Fp2>, Montgomery form; with pre_c != 0 it is the table
                             // [W][n]: slice w holds 2^(pre_c * w) * P  (vsp_bases_precompute)
     unsigned pre_c = 0;
+    int in_subgroup = 0;    // 1: every point satisfies phi(P) = lambda P (checked at upload, or the library's own multiples of a generator); -1: the check
+                            // found a point that does not; 0: not checked.  The endomorphism layout below needs 1 (or option "msm_glv" = 2)
     bool glv = false;       // plain bases only: d28 holds 2n rows, (P_i, phi(P_i)) interleaved, phi(x, y) = (beta x, y) = lambda * P (the curve's
                             // endomorphism): a scalar k = k1 + k2 lambda then needs windows over 128 bits only -- half the bucket sets to reduce
     void *d28 = nullptr;    // the same array (or table) once more on 14 x 28-bit limbs (fp28.h: 112-byte rows G1, 224-byte rows G2) for the accumulation kernel
@@ -175,6 +183,7 @@ int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
 // ---- internal entry points (each implemented in its own .hip) ----
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
 int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m);
+void ntt_selfcheck_once(vsp_ctx *ctx);                          // known-answer check of the 29-bit butterfly kernel, before any table set-up
 int ntt_ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4);
 // evaluation domains (domain.hip)
 int domain_init(vsp_ctx *ctx, vsp_domain *d, size_t min_size);      // make_evaluation_domain's choice + the coset divisors
@@ -211,6 +220,14 @@ void msm_drain_slots(vsp_ctx *ctx);
 // d_flag: one device word, zeroed by the caller; bit 0 = coordinate >= p, bit 1 = point off the curve (only when check_curve)
 int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);
 int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);
+// raises bit 2 of *d_flag when some point fails phi(P) = lambda P (the endomorphism split's precondition; msm_impl.inc k_subgroup_check)
+int subgroup_check_g1(vsp_ctx *ctx, const G1Affine *d_mont, size_t n, uint32_t *d_flag);
+int subgroup_check_g2(vsp_ctx *ctx, const G2Affine *d_mont, size_t n, uint32_t *d_flag);
+// resident bases from canonical points; trust: BASES_CALLER = caller data (validated; the split only after the subgroup check),
+// BASES_OWN = points this library computed as multiples of a generator (in the subgroup by construction: no check),
+// BASES_TRANSIENT = bases of one host-buffer call, or bases about to get window multiples (no split, so no check: exact for any curve point)
+enum { BASES_CALLER = 0, BASES_OWN = 1, BASES_TRANSIENT = 2 };
+vsp_bases *bases_create(vsp_ctx *ctx, int group, const void *src, bool src_on_device, size_t n, int trust);
 int fixed_base_mul_g1(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
 int fixed_base_mul_g2(vsp_ctx *ctx, const Fr *d_scalars, size_t n, void *d_out);
 int upload_power_tables(vsp_ctx *ctx, const HFr &base, size_t hi_count, DevBuf &lo, DevBuf &hi);

@@ -234,6 +234,7 @@ HFr domain_element(const vsp_domain *d, size_t idx) {
 int domain_fft_device(vsp_ctx *ctx, const vsp_domain *d, Fr *a, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
     if (!d->step) return ntt_device(ctx, a, d->log_big, inverse, coset_g, extra_scale);
     if (coset_g && !(coset_g[0] | coset_g[1] | coset_g[2] | coset_g[3])) return set_error(ctx, VSP_ERR_ARG, "fft: coset generator is zero");
+    ntt_selfcheck_once(ctx);
     const size_t big = d->big_m, small = d->small_m, compr = big / small;
     VSP_TRY(ntt_ensure_twiddles(ctx, d->log_big + 1));
     if (coset_g) VSP_TRY(ntt_ensure_coset_tables(ctx, d->log_big + 1, coset_g));

@@ -134,7 +134,7 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
         if (ensure(ctx, pts, (qs[i].n ? qs[i].n : 1) * esz) != VSP_OK) return fail(nullptr);
         int rc = qs[i].group == 1 ? fixed_base_mul_g1(ctx, qs[i].sc, qs[i].n, pts.p) : fixed_base_mul_g2(ctx, qs[i].sc, qs[i].n, pts.p);
         if (rc != VSP_OK) return fail(nullptr);
-        kp->q[i] = qs[i].group == 1 ? vsp_bases_from_device_g1(ctx, pts.p, qs[i].n) : vsp_bases_from_device_g2(ctx, pts.p, qs[i].n);
+        kp->q[i] = bases_create(ctx, qs[i].group, pts.p, true, qs[i].n, BASES_OWN);      // multiples of the generators: in the subgroup by construction
         if (!kp->q[i]) return fail(nullptr);
         // precompute: bit 0 = the recommended set A, B(G1), B(G2), L; bits 1..5 select A, B(G1), B(G2), H, L one by one.  H stays plain
         // in the recommended set: its scalars are dense, so the window size does not shrink, the bucket reduction over 16 window sets is

@@ -404,6 +404,56 @@ static Fr29 host_to_fr29_mont(const HFr &x) {          // host value (Montgomery
     return r;
 }
 
+// Known-answer check of the 29-bit-limb butterflies THROUGH k_ntt29_pass (its product, vsp_mm29, is a hand-laid-out routine with a private
+// calling convention: see the note at capi.hip fp28_known_answer_check).  Once per context, before the first transform on that path: a
+// 2^13-point vector (two passes: the lazy planes between passes, the first and the last pass) goes through a forward coset transform
+// and an inverse coset transform on k_ntt29_pass and on the 8 x 32-bit k_ntt_pass; the outputs must agree word for word.  On a
+// mismatch the context falls back to the 8 x 32-bit kernel ("ntt_fr29" = 0) for its lifetime.
+static bool ntt29_known_answer_check(vsp_ctx *ctx) {
+    if (ctx->ntt29_checked != 0) return ctx->ntt29_checked == 1;
+    ctx->ntt29_checked = 2;                                   // in progress: the transforms below must not re-enter
+    const unsigned lg = 13; const size_t n = (size_t)1 << lg, bytes = n * sizeof(Fr);
+    std::vector<uint64_t> h(n * 4), o29(n * 4), o32(n * 4);
+    uint64_t x = 0x243F6A8885A308D3ULL;
+    auto next = [&]() { x += 0x9E3779B97F4A7C15ULL; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
+    for (size_t i = 0; i < n; i++) { h[4 * i] = next(); h[4 * i + 1] = next(); h[4 * i + 2] = next(); h[4 * i + 3] = next() >> 2; }
+    h[0] = h[1] = h[2] = h[3] = 0;                            // a zero and r - 1 among them
+    h[4] = 0xffffffff00000000ULL; h[5] = 0x53bda402fffe5bfeULL; h[6] = 0x3339d80809a1d805ULL; h[7] = 0x73eda753299d7d48ULL;
+    const uint64_t g7[4] = {7, 0, 0, 0};
+    void *d = nullptr;
+    bool ran = false, same = true;
+    const bool had = ctx->opts.count("ntt_fr29") != 0; const long saved = had ? ctx->opts["ntt_fr29"] : 1;
+    if (hipMalloc(&d, bytes) == hipSuccess) {
+        ran = true;
+        for (int inverse = 0; inverse < 2 && ran; inverse++) {
+            for (int path = 0; path < 2 && ran; path++) {
+                ctx->opts["ntt_fr29"] = path == 0 ? 1 : 0;
+                std::vector<uint64_t> &out = path == 0 ? o29 : o32;
+                ran = hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                      ntt_device(ctx, (Fr *)d, lg, inverse, g7, nullptr) == VSP_OK &&
+                      hipMemcpyAsync(out.data(), d, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                      hipStreamSynchronize(ctx->stream) == hipSuccess;
+            }
+            if (ran && memcmp(o29.data(), o32.data(), bytes) != 0) same = false;
+        }
+        hipFree(d);
+    }
+    if (had) ctx->opts["ntt_fr29"] = saved; else ctx->opts.erase("ntt_fr29");
+    hipGetLastError();
+    if (!ran) { ctx->ntt29_checked = 0; ctx->stats["ntt_fr29_selfcheck"] = 0.0; return false; }      // could not run: no verdict, the 8 x 32-bit kernel this time
+    { auto it = ctx->opts.find("ntt_fr29_selfcheck_fault"); if (it != ctx->opts.end() && it->second) same = false; }      // test hook: exercise the fallback
+    ctx->ntt29_checked = same ? 1 : -1;
+    ctx->stats["ntt_fr29_selfcheck"] = same ? 1.0 : -1.0;
+    if (!same) { ctx->opts["ntt_fr29"] = 0; ctx->err = "ntt: the 29-bit-limb butterfly kernel failed its known-answer check; 8 x 32-bit kernel in use"; }
+    return same;
+}
+
+// callers that set tables up before their first transform (the step-domain glue) run the check first: it rebuilds tables for its own use
+void ntt_selfcheck_once(vsp_ctx *ctx) {
+    long want29 = 1; auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) want29 = it->second;
+    if (want29 && ctx->ntt29_checked == 0) ntt29_known_answer_check(ctx);
+}
+
 // d_a: n canonical Fr values in device memory, transformed in place.
 // extra_scale (optional, host Montgomery): an additional constant multiplied into every output.
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
@@ -412,6 +462,10 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
         uint64_t z = coset_g[0] | coset_g[1] | coset_g[2] | coset_g[3];
         if (!z) return set_error(ctx, VSP_ERR_ARG, "ntt: coset generator is zero");
     }
+    // the 29-bit path's known-answer check comes first: it runs transforms of its own, which may rebuild the twiddle and coset tables
+    bool check29_ok = true;
+    { long want29 = 1; auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) want29 = it->second;
+      if (want29 && ctx->ntt29_checked <= 0) check29_ok = ntt29_known_answer_check(ctx); }      // (2 = the check itself is running: not re-entered)
     VSP_TRY(ntt_ensure_twiddles(ctx, log_m));
     if (coset_g) VSP_TRY(ntt_ensure_coset_tables(ctx, log_m, coset_g));
     const size_t n = (size_t)1 << log_m;
@@ -427,6 +481,7 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
                 if ((stages[k] & 1) && stages[i] < NTT_MAX_STAGES && stages[k] > 1) { stages[i]++; stages[k]--; break; }
 
     long use29 = 1; { auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) use29 = it->second; }
+    if (use29 && !check29_ok) use29 = 0;
     Fr *scratch = nullptr;
     if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * (use29 ? 36 : sizeof(Fr)))); scratch = (Fr *)ctx->ntt_scratch.p; }
 

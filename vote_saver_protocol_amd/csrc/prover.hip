@@ -53,6 +53,15 @@ vsp_r1cs *vsp_r1cs_upload(vsp_ctx *ctx, size_t num_constraints, size_t num_input
     if (domain_init(ctx, &cs->dom, num_constraints + num_inputs + 1) != VSP_OK) { delete cs; return nullptr; }
     const uint32_t *rp[3] = {row_ptr_a, row_ptr_b, row_ptr_c}, *ci[3] = {col_a, col_b, col_c};
     const uint64_t *co[3] = {coef_a, coef_b, coef_c};
+    for (int m = 0; m < 3; m++) {                             // every matrix before anything is allocated: row pointers monotone from 0, arrays present
+        const size_t nnz = rp[m][num_constraints];
+        bool mono = rp[m][0] == 0;
+        for (size_t r = 0; r < num_constraints && mono; r++) mono = rp[m][r] <= rp[m][r + 1];
+        if (!mono || (nnz && (!ci[m] || !co[m]))) {
+            set_error(ctx, VSP_ERR_ARG, !mono ? "r1cs_upload: row pointers must start at 0 and not decrease" : "r1cs_upload: null column / coefficient array with nnz > 0");
+            vsp_r1cs_free(ctx, cs); return nullptr;
+        }
+    }
     for (int m = 0; m < 3; m++) {
         size_t nnz = rp[m][num_constraints];
         for (size_t e = 0; e < nnz; e++) if (ci[m][e] > num_vars) { set_error(ctx, VSP_ERR_ARG, "r1cs_upload: column out of range"); vsp_r1cs_free(ctx, cs); return nullptr; }

@@ -78,6 +78,14 @@ static bool g1_valid(const uint64_t *p) {
     HFp four = dbl(dbl(HFp::one()));
     return eq(sqr(a.y), add(mul(sqr(a.x), a.x), four));
 }
+static bool g2_valid(const uint64_t *p) {                      // coordinates below p, on y^2 = x^3 + 4 (1 + u) (all zero = infinity)
+    auto below_p = [](const uint64_t *l) { for (int i = 5; i >= 0; i--) { if (l[i] < FpP64::MOD[i]) return true; if (l[i] > FpP64::MOD[i]) return false; } return false; };
+    for (int k = 0; k < 4; k++) if (!below_p(p + 6 * k)) return false;
+    Affine<HFp2> a = host_load_g2(p);
+    if (is_inf(a)) return true;
+    HFp2 b; b.c0 = dbl(dbl(HFp::one())); b.c1 = b.c0;
+    return eq(sqr(a.y), add(mul(sqr(a.x), a.x), b));
+}
 
 }  // namespace vsp
 
@@ -211,7 +219,8 @@ int vsp_saver_rerandomize(vsp_ctx *ctx, const vsp_saver_pk *spk, const uint64_t 
     HFr a = host_load_canon<HFr>(z1), b = host_load_canon<HFr>(z2);
     if (is_zero(a)) return set_error(ctx, VSP_ERR_ARG, "saver_rerandomize: z1 must be invertible");
     for (size_t i = 0; i < n + 2; i++) if (!g1_valid(ct + 12 * i)) return set_error(ctx, VSP_ERR_ARG, "saver_rerandomize: a ciphertext element is not a curve point");
-    if (!g1_valid(A) || !g1_valid(C)) return set_error(ctx, VSP_ERR_ARG, "saver_rerandomize: a proof element is not a curve point");
+    if (!g1_valid(A) || !g1_valid(C) || !g2_valid(B)) return set_error(ctx, VSP_ERR_ARG, "saver_rerandomize: a proof element is not a curve point");
+    if (!g2_valid(delta_g2)) return set_error(ctx, VSP_ERR_ARG, "saver_rerandomize: delta_g2 is not a curve point");
     uint64_t zi4[4], zz4[4];
     host_store_canon(zi4, inv(a)); host_store_canon(zz4, mul(a, b));
     // the four one-off scalar multiplications are independent: the two in G2 (the long ones) run beside the G1 work

@@ -31,15 +31,21 @@ __device__ __forceinline__ Fp fp_from_be(const uint32_t *w, bool first) {
     if (first) r.l[11] &= 0x1FFFFFFFu;
     return r;
 }
-// ZCash uncompressed records -> canonical affine points (infinity flag -> all zero); flag bit 2: a record claims to be compressed
+// ZCash uncompressed records -> canonical affine points (infinity flag -> all zero).  flag bit 2: a record is malformed -- it claims to be
+// compressed (0x80), carries the sign bit that only the compressed form has (0x20), or is an infinity record (0x40) with a non-zero payload
+__device__ __forceinline__ bool record_rest_zero(const uint32_t *w, unsigned words) {
+    uint32_t acc = w[0] & ~0xFFu;                              // everything but the flag byte
+    for (unsigned j = 1; j < words; j++) acc |= w[j];
+    return acc == 0 && (w[0] & 0x3Fu) == 0;
+}
 __global__ __launch_bounds__(256) void k_g1_from_be(const uint8_t *src, size_t stride, size_t n, G1Affine *out, uint32_t *flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t *w = (const uint32_t *)(src + i * stride);
     const uint32_t head = w[0] & 0xFFu;                       // first byte of the record
     G1Affine p;
-    if (head & 0x80u) atomicOr(flag, 4u);
-    if (head & 0x40u) { p.x = Fp::zero(); p.y = Fp::zero(); }
+    if (head & 0xA0u) atomicOr(flag, 4u);
+    if (head & 0x40u) { p.x = Fp::zero(); p.y = Fp::zero(); if (!record_rest_zero(w, 24)) atomicOr(flag, 4u); }
     else { p.x = fp_from_be(w, true); p.y = fp_from_be(w + 12, false); }
     out[i] = p;
 }
@@ -49,8 +55,8 @@ __global__ __launch_bounds__(256) void k_g2_from_be(const uint8_t *src, size_t s
     const uint32_t *w = (const uint32_t *)(src + i * stride);
     const uint32_t head = w[0] & 0xFFu;
     G2Affine p;
-    if (head & 0x80u) atomicOr(flag, 4u);
-    if (head & 0x40u) { p.x.c0 = p.x.c1 = p.y.c0 = p.y.c1 = Fp::zero(); }
+    if (head & 0xA0u) atomicOr(flag, 4u);
+    if (head & 0x40u) { p.x.c0 = p.x.c1 = p.y.c0 = p.y.c1 = Fp::zero(); if (!record_rest_zero(w, 48)) atomicOr(flag, 4u); }
     else { p.x.c1 = fp_from_be(w, true); p.x.c0 = fp_from_be(w + 12, false); p.y.c1 = fp_from_be(w + 24, false); p.y.c0 = fp_from_be(w + 36, false); }
     out[i] = p;
 }
@@ -122,7 +128,7 @@ int vsp_proof_from_blob(const uint8_t blob[192], int check_subgroup, uint64_t A[
 }
 int vsp_proof_to_blob(const uint64_t A[12], const uint64_t B[24], const uint64_t C[12], uint8_t out[192]) {
     if (!A || !B || !C || !out) return VSP_ERR_ARG;
-    vsp_g1_compress(A, out); vsp_g2_compress(B, out + 48); vsp_g1_compress(C, out + 144);
+    if (vsp_g1_compress(A, out) != VSP_OK || vsp_g2_compress(B, out + 48) != VSP_OK || vsp_g1_compress(C, out + 144) != VSP_OK) return VSP_ERR_ARG;
     return VSP_OK;
 }
 
@@ -136,10 +142,10 @@ int vsp_vk_to_blob(uint32_t head, const uint8_t gt[576], const uint64_t gamma_g2
     for (int i = 0; i < 4; i++) out[i] = (uint8_t)(head >> (24 - 8 * i));
     memcpy(out + 4, gt, 576);
     uint8_t *p = out + 580;
-    vsp_g2_compress(gamma_g2, p); vsp_g2_compress(delta_g2, p + 96); vsp_g1_compress(delta_g1, p + 192);
+    if (vsp_g2_compress(gamma_g2, p) != VSP_OK || vsp_g2_compress(delta_g2, p + 96) != VSP_OK || vsp_g1_compress(delta_g1, p + 192) != VSP_OK) return VSP_ERR_ARG;
     put_be64(p + 240, n_abc);
-    for (size_t i = 0; i < n_abc; i++) vsp_g1_compress(gamma_abc_g1 + 12 * i, p + 248 + 48 * i);
-    vsp_g1_compress(gamma_g1, p + 248 + 48 * n_abc);
+    for (size_t i = 0; i < n_abc; i++) if (vsp_g1_compress(gamma_abc_g1 + 12 * i, p + 248 + 48 * i) != VSP_OK) return VSP_ERR_ARG;
+    if (vsp_g1_compress(gamma_g1, p + 248 + 48 * n_abc) != VSP_OK) return VSP_ERR_ARG;
     return VSP_OK;
 }
 int vsp_vk_from_blob(const uint8_t *blob, size_t len, int check_subgroup, uint32_t *head, uint8_t gt[576], uint64_t gamma_g2[24], uint64_t delta_g2[24],
@@ -239,16 +245,23 @@ vsp_keypair *vsp_pk_from_blob(vsp_ctx *ctx, const uint8_t *blob, size_t len, int
             else hipLaunchKernelGGL(k_g2_from_be, dim3(blk), dim3(256), 0, st, src, rec[pt.sec], n, (G2Affine *)d_pts, (uint32_t *)ctx->val_flag.p);
             uint32_t h_flag = 0;
             ok = hipMemcpyAsync(&h_flag, ctx->val_flag.p, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-            if (ok && h_flag) { set_error(ctx, VSP_ERR_ARG, "pk_from_blob: a point record is not in uncompressed form"); ok = false; break; }
+            if (ok && h_flag) { set_error(ctx, VSP_ERR_ARG, "pk_from_blob: a point record is not a well-formed uncompressed record (compressed form, stray flag bits, or an infinity record with a payload)"); ok = false; break; }
         }
         if (ok) {
-            kp->q[pt.q] = pt.group == 1 ? vsp_bases_from_device_g1(ctx, d_pts, n) : vsp_bases_from_device_g2(ctx, d_pts, n);   // curve check, Montgomery, 28-bit table
+            // curve check, Montgomery form, 28-bit table; wire bytes are caller data: the endomorphism layout only after the subgroup check
+            // (a query that gets window multiples below never uses that layout: BASES_TRANSIENT skips the layout and its check)
+            const bool pre_this = ((precompute & 1) && pt.q != 3) || ((precompute >> (pt.q + 1)) & 1);
+            kp->q[pt.q] = bases_create(ctx, pt.group, d_pts, true, n, pre_this ? BASES_TRANSIENT : BASES_CALLER);
             ok = kp->q[pt.q] != nullptr;
-            if (ok && precompute) ok = vsp_bases_precompute(ctx, kp->q[pt.q], 0) == VSP_OK;
         }
     }
     hipStreamSynchronize(st);
-    hipFree(d_raw); hipFree(d_pts);
+    hipFree(d_raw); hipFree(d_pts);         // before the window multiples are built: the raw blob (0.6 GB at 2^20 constraints) is no longer needed
+    // precompute: the bit mask of vsp_groth16_generate -- bit 0 = the recommended set A, B(G1), B(G2), L (H stays plain); bits 1..5 = A, B(G1), B(G2), H, L
+    for (int i = 0; i < 5 && ok; i++) {
+        const bool pre_this = ((precompute & 1) && i != 3) || ((precompute >> (i + 1)) & 1);
+        if (pre_this) ok = vsp_bases_precompute(ctx, kp->q[i], 0) == VSP_OK;
+    }
     if (ok) {
         // the five single elements on the host (uncompressed records; infinity is not a valid key element)
         auto g1 = [&](const uint8_t *p, uint64_t *o) { if (p[0] & 0xC0) return false; uint8_t t[96]; memcpy(t, p, 96); limbs_from_be(o, t, 6); limbs_from_be(o + 6, t + 48, 6); return true; };
