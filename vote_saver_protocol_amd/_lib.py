@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvsp_hip.so")
+# VSP_LIB_PATH: a variant build of the same library (diagnostic / experiment builds made by `make OUT=... EXTRA=...`); never a fallback
+SO_PATH = os.environ.get("VSP_LIB_PATH") or os.path.join(_HERE, "libvsp_hip.so")
 
 _P = C.c_void_p
 _SZ = C.c_size_t
