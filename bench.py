@@ -45,7 +45,12 @@ R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_PAIR = {1: 128, 2: 224}   # affine base (96 / 192 B) + 32 B scalar
 MADS_PER_ADD = {1: 6 * 392 + 2 * 301 + 588, 2: 2 * (8 * 588 + 2 * 392)}   # v_mad_u64_u32 per mixed addition: 6 products, 2 squares, 1 dual product (G2: two lanes per point)
-VALU_PEAK_MADS = 1.46e9 * 64 * 256  # measured v_mad_u64_u32 issue peak (profiles/r1_ubench_valu.txt): wave-instr/s/CU x lanes x CUs
+# Issue cost of a SIMD per wave-instruction, in SHADER CYCLES, with >= 3 waves on the SIMD (tools/ubench_issue.hip, profiles/r3_ubench_issue.txt:
+# every wave stamps s_memtime, a SIMD's cost = (last wave's end - first wave's start) / instructions of all its waves): the dependent chain of
+# v_mad_u64_u32 the product routines are, and the simple 32-bit VALU instructions around it.  (The figure of rounds 1-2 -- 6.6 cycles -- came from
+# tools/ubench_valu.hip, whose separate asm statements let the compiler put an s_nop after every multiply-add, and was priced in wall time at the nominal clock.)
+ISSUE_CYCLES_FALLBACK = {"mad": 4.59, "simple": 2.88}
+N_SIMD = 1024
 PMC_FILES = ("r2_pmc_hbm_traffic.json", "r1_h_pmc_hbm_traffic.json")   # newest first; see profiles/README.md
 
 
@@ -95,6 +100,48 @@ def bench_prove_step_domain(ctx, v, cref, o, precompute=True):
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
     out = {"prove_step_domain_constraints": nc, "prove_step_domain_m": int(dcs.m), "prove_step_domain_kind": dcs.domain_kind,
            "prove_step_domain_ms": dt * 1e3, "prove_step_domain_pairing_verified": bool(ok)}
+    kp.free(); dcs.free(); cs.free()
+    return out
+
+
+def bench_prove_small(ctx, v, cref, o, log_m=16, precompute=True):
+    """Proofs per second at the real circuit's likely size (depth 20 over a Pedersen / Jubjub Merkle path is 2^15..2^16
+    constraints): latency of one proof, then 1..4 host threads with a context each over ONE resident key."""
+    import threading
+    ni = 30
+    nc = (1 << log_m) - ni - 2
+    gen = o.splitmix64(16)
+    cs, wit = cref.R1CS.synth(nc, ni, 40, ballot=(25, 3))
+    tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
+    kp = v.Keypair(ctx, dcs, tox, precompute=precompute)
+    r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
+    wit = ctx.host_register(np.ascontiguousarray(wit))
+    ref = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_)
+    each = []
+    for _ in range(20):
+        t0 = time.perf_counter(); v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_); each.append(time.perf_counter() - t0)
+    out = {f"prove_2p{log_m}_ms": float(np.median(each)) * 1e3, f"prove_2p{log_m}_constraints": nc, f"prove_2p{log_m}_key_bytes": int(kp.device_bytes())}
+    ctxs = [ctx] + [v.Context(ctx.device) for _ in range(3)]
+    for c in ctxs[1:]:
+        v.groth16_prove(c, dcs, kp.pk, wit, r, s_)
+    per_thread, same = 40, True
+    for k in (1, 2, 3, 4):
+        res = {}
+
+        def worker(c, tag):
+            for _ in range(per_thread):
+                res[tag] = v.groth16_prove(c, dcs, kp.pk, wit, r, s_)
+        th = [threading.Thread(target=worker, args=(c, i)) for i, c in enumerate(ctxs[:k])]
+        t0 = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        out[f"prove_2p{log_m}_{k}_contexts_proofs_per_s"] = k * per_thread / (time.perf_counter() - t0)
+        same = same and all(res[i][3] == ref[3] for i in range(k))
+    out[f"prove_2p{log_m}_contexts_same_proof"] = bool(same)
+    for c in ctxs[1:]:
+        c.close()
+    ctx.host_unregister(wit)
     kp.free(); dcs.free(); cs.free()
     return out
 
@@ -153,11 +200,36 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     same = all(np.array_equal(outs[i][0], pa) and np.array_equal(outs[i][1], pb) and np.array_equal(outs[i][2], pc) for i in range(n_ctx))
     for c in extra_ctx:
         c.close()
+    # ---- the same prover on a DENSE witness (every wire a uniform field element: no zeros, no ones -- the all-ones bucket and the small windows
+    #      of a boolean witness are gone, every witness multi-exponentiation is a full-width one).  Not a satisfying assignment: timing only.
+    dense = ctx.host_register(rand_fr(cs.num_vars, 99))
+    v.groth16_prove(ctx, dcs, pk, dense, r, s_)
+    td = []
+    for _ in range(5):
+        t0 = time.perf_counter(); v.groth16_prove(ctx, dcs, pk, dense, r, s_); td.append(time.perf_counter() - t0)
+    ctx.host_unregister(dense)
+    dense_ms = float(np.median(td)) * 1e3
+    del dense
+    key_bytes = kp.device_bytes()
+    # ---- the reference parses the proving key INSIDE its timed vote phase (main.cpp:446-456 around common.hpp:1002-1006): the "fast" blob of this
+    #      very key -> a resident key, converted on the GPU (byte order, curve check, subgroup policy, Montgomery form, 28-bit tables, window multiples)
+    pk_load = {}
+    try:
+        blob = kp.to_blob()
+        t0 = time.perf_counter(); k2 = v.Keypair.from_blob(ctx, blob, precompute=precompute); pk_load_s = time.perf_counter() - t0
+        pa2, pb2, pc2, _ = v.groth16_prove(ctx, dcs, k2.pk, wit, r, s_)
+        pk_load = {f"pk_from_blob_2p{log_m}_s": pk_load_s, f"pk_blob_2p{log_m}_bytes": len(blob),
+                   f"pk_from_blob_2p{log_m}_same_proof": bool(np.array_equal(pa2, pa) and np.array_equal(pb2, pb) and np.array_equal(pc2, pc)),
+                   f"pk_from_blob_2p{log_m}_subgroup_checks": ctx.stat("bases_subgroup_checks")}
+        k2.free(); del blob
+    except Exception as e:
+        pk_load = {f"pk_from_blob_2p{log_m}_error": repr(e)}
     vk = dict(alpha_g1=o.g1_from_limbs(alpha_g1), beta_g2=o.g2_from_limbs(beta_g2), gamma_g2=o.g2_from_limbs(gamma_g2),
               delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in gamma_abc])
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
-    out = {f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
+    out = {f"prove_2p{log_m}_dense_witness_ms": dense_ms, f"prove_2p{log_m}_key_bytes": int(key_bytes), **pk_load,
+           f"prove_2p{log_m}_ms": dt * 1e3, f"prove_2p{log_m}_proofs_per_s": 1.0 / dt, f"prove_2p{log_m}_pairing_verified": bool(ok),
            f"prove_2p{log_m}_constraints": nc, f"generate_2p{log_m}_gpu_s": setup_s, f"prove_2p{log_m}_key_precomputed": bool(precompute),
            f"prove_2p{log_m}_phase_ms": phases,
            f"prove_2p{log_m}_ms_mean_max": [float(np.mean(each)) * 1e3, float(np.max(each)) * 1e3], f"prove_2p{log_m}_two_contexts_ms_per_proof": dt2 * 1e3, f"prove_2p{log_m}_two_contexts_proofs_per_s": 1.0 / dt2,
@@ -188,6 +260,10 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
         out.update({f"vote_phase_2p{log_m}_encrypt_ms": t_enc / reps * 1e3, f"vote_phase_2p{log_m}_rerandomize_ms": t_rer / reps * 1e3,
                     f"vote_phase_2p{log_m}_ms": (t_enc + t_rer) / reps * 1e3, f"vote_phase_2p{log_m}_msg_size": nmsg,
                     f"vote_phase_2p{log_m}_pk_load_once_s": load_s, f"vote_phase_2p{log_m}_verify_encryption": bool(okv)})
+        if f"pk_from_blob_2p{log_m}_s" in out:
+            # the reference's timed region (main.cpp:446-456): deserialise the keys, then encrypt + rerandomize -- here: proving-key blob -> resident key on
+            # the GPU, the SAVER key's fixed-base tables, one vote.  (Circuit construction and witness generation, also inside the reference's region, are out of scope.)
+            out[f"vote_phase_2p{log_m}_including_key_load_ms"] = (out[f"pk_from_blob_2p{log_m}_s"] + load_s) * 1e3 + (t_enc + t_rer) / reps * 1e3
         spk.free()
     except Exception as e:                         # secondary measurement: never take the bench line down
         out[f"vote_phase_2p{log_m}_error"] = repr(e)
@@ -217,6 +293,77 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     pk2.free(); dcs2.free(); [q.free() for q in q2]; kp.free(); cs2.free()
     return out
 
+
+
+def issue_costs():
+    """cycles of a SIMD per wave-instruction from the committed microbenchmark output (4 waves per SIMD rows), else the fallback constants"""
+    out, src = dict(ISSUE_CYCLES_FALLBACK), "bench.py constants"
+    try:
+        import re
+        txt = open(os.path.join(ROOT, "profiles", "r3_ubench_issue.txt")).read()
+        def grab(label):
+            m = re.search(re.escape(label) + r"\s+4 wave/SIMD.*?with 4 waves: ([0-9.]+) cycles", txt)
+            return float(m.group(1)) if m else None
+        a, b = grab("v_mad_u64_u32 (VCC, ONE dependent chain, as the routines)"), grab("v_add_u32")
+        if a and b:
+            out, src = {"mad": a, "simple": b}, "profiles/r3_ubench_issue.txt (tools/ubench_issue.hip, 4 waves per SIMD)"
+    except Exception:
+        pass
+    return out, src
+
+
+def accum_instr_mix():
+    """the instruction mix of ONE iteration (one mixed addition) of the generated G1 accumulation loop, counted from the generator's own
+    instruction list (tools/gen_accum28_asm.py): multiply-adds, other VALU, SALU, VMEM"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_accum28_asm", os.path.join(ROOT, "tools", "gen_accum28_asm.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    ins = g.gen_body()
+    a, b = ins.index(".Lvsp_acc28_loop:"), max(i for i, x in enumerate(ins) if x.startswith("s_cbranch_scc1 .Lvsp_acc28_loop"))
+    body = [x for x in ins[a:b + 1] if not x.endswith(":")]
+    init = ins.index(".Lvsp_acc28_noinit:")                     # the first-point branch is taken once per part, not per addition
+    skip = set(range(max(i for i, x in enumerate(ins[:init]) if x.startswith("s_cbranch_scc0 .Lvsp_acc28_noinit")) + 1, init))
+    body = [x for i, x in enumerate(ins[a:b + 1], a) if not x.endswith(":") and i not in skip]
+    mix = {"v_mad_u64_u32": sum(x.startswith("v_mad_u64_u32") for x in body), "valu_other": sum(x.startswith("v_") and not x.startswith("v_mad_u64_u32") for x in body),
+           "salu": sum(x.startswith("s_") for x in body), "vmem": sum(x.startswith("global_") for x in body)}
+    return mix
+
+
+def diag_clock_ghz(dev_index, d_bases_canon, n, d_scalars_ptr, seconds=2.0):
+    """The clock the chip holds inside the G1 accumulation loop (MI355X_MICROARCH.md, DVFS item 6): the DIAGNOSTIC build of the same
+    sources (libvsp_hip_diag.so: s_memtime / s_memrealtime stamps around the loop; the shipped library executes no stamp) runs the
+    headline multi-exponentiation back to back for `seconds` on the same bases and scalars.  None when that build is absent."""
+    import ctypes as C
+    from vote_saver_protocol_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.SO_PATH), "libvsp_hip_diag.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    for name in ("vsp_create", "vsp_destroy", "vsp_bases_from_device_g1", "vsp_bases_free", "vsp_msm_resident", "vsp_diag_clock", "vsp_last_error"):
+        fn = getattr(lib, name); fn.restype, fn.argtypes = _lib.PROTOTYPES[name]
+    ctx = lib.vsp_create(dev_index)
+    if not ctx:
+        return None
+    try:
+        b = lib.vsp_bases_from_device_g1(ctx, C.c_void_p(d_bases_canon), n)
+        if not b:
+            return None
+        out = np.zeros(12, np.uint64); inf = C.c_int(0)
+        run = lambda: lib.vsp_msm_resident(ctx, b, 0, n, C.c_void_p(d_scalars_ptr), out.ctypes.data_as(C.c_void_p), C.byref(inf))
+        for _ in range(3):
+            run()
+        ghz, waves = C.c_double(0), C.c_double(0)
+        lib.vsp_diag_clock(ctx, 1, C.byref(ghz), C.byref(waves))          # reset after the warm-up
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            if run() != 0:
+                return None
+            k += 1
+        rc = lib.vsp_diag_clock(ctx, 0, C.byref(ghz), C.byref(waves))
+        lib.vsp_bases_free(ctx, b)
+        return {"ghz": ghz.value, "waves_stamped": waves.value, "msms": k, "seconds": time.perf_counter() - t0} if rc == 0 and ghz.value > 0 else None
+    finally:
+        lib.vsp_destroy(ctx)
 
 
 def host_cores():
@@ -366,6 +513,7 @@ def main():
     ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
+    ap.add_argument("--no-diag-clock", action="store_true", help="skip the 2 s in-kernel clock leg (diagnostic build of the library)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend of the exchange step: nccl = RCCL over xGMI (device buffers); gloo = host buffers (rehearsals)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
@@ -528,14 +676,38 @@ def main():
                       "ms_per_step_same_mode; avg_launch_ms_pipelined is the same bracket inside the timed region, where neighbouring steps' kernels share "
                       "the GPU.  The kernel is integer-issue bound (about 160 Montgomery products per point), not HBM bound: see roofline_valu.  traffic is "
                       "not measurable in-process (PMC passes need rocprofv3): it is read from traffic_source"}
-        rv = {"bound": "v_mad_u64_u32 issue", "kernel": rl["kernel"], "achieved": mads / (excl_ms * 1e-3) / 1e12, "peak": VALU_PEAK_MADS / 1e12,
-              "unit": "T v_mad_u64_u32 lane-ops/s", "frac": mads / (excl_ms * 1e-3) / VALU_PEAK_MADS, "mads_per_mixed_addition": MADS_PER_ADD[group],
-              "mixed_additions_per_launch": n_points * (2 if split else 1) * windows, "endomorphism_split": bool(split), "peak_source": "profiles/r2_ubench_valu.txt (tools/ubench_valu.hip, measured on one MI355X of the pool; boxes differ by a few per cent in clock, so frac reads 0.91-1.02 for one build)"}
+        # the bound that applies: VALU issue.  One iteration of the generated loop = one mixed addition of a whole wave; its instruction mix is
+        # counted from the generator's own list, priced with the SIMD's measured issue cost per instruction class (shader cycles, >= 3 waves
+        # per SIMD) -- that is the peak: cycles a SIMD cannot go below for this instruction stream.  The kernel's cycles come from its
+        # duration and the clock the chip HELD inside the loop (diagnostic build, same run), so the fraction cannot exceed 1 by a clock or
+        # a denominator artefact.  G2 (lane pairs, compiler-allocated kernel): the multiply-adds alone at the same issue cost.
+        adds = n_points * (2 if split else 1) * windows
+        costs, cost_src = issue_costs()
+        wave_adds_per_simd = adds * (2 if group == 2 else 1) / 64.0 / N_SIMD          # G2: two lanes per point
+        if group == 1:
+            mix = accum_instr_mix()
+            ideal_cycles = mix["v_mad_u64_u32"] * costs["mad"] + mix["valu_other"] * costs["simple"]
+        else:
+            mix = {"v_mad_u64_u32": MADS_PER_ADD[2] // 2, "valu_other": None, "note": "per lane of a pair; the rest of the compiler-allocated loop is not priced (a looser peak)"}
+            ideal_cycles = mix["v_mad_u64_u32"] * costs["mad"]
+        clk = clock_info["ghz"] if clock_info else None
+        kernel_cycles = (excl_ms * 1e-3 * clk * 1e9 / wave_adds_per_simd) if clk else None
+        rv = {"bound": "VALU issue (one wave-instruction per SIMD every 4.6 cycles for v_mad_u64_u32, 2.9 for simple 32-bit ops)", "kernel": rl["kernel"],
+              "unit": "shader cycles of a SIMD per mixed addition of a wave", "peak": ideal_cycles, "achieved": kernel_cycles,
+              "frac": (ideal_cycles / kernel_cycles) if kernel_cycles else None,
+              "instr_mix": mix, "issue_cycles_per_wave_instruction": costs, "issue_cost_source": cost_src,
+              "clock_ghz_in_kernel": clk, "clock_source": ("libvsp_hip_diag.so: delta s_memtime / delta s_memrealtime x 100 MHz around the loop, summed over %d waves of %d "
+                                                           "back-to-back multi-exponentiations in this run" % (clock_info["waves_stamped"], clock_info["msms"])) if clock_info else
+                                                          "diagnostic build absent: no in-kernel clock, no fraction",
+              "mixed_additions_per_launch": adds, "wave_additions_per_simd": wave_adds_per_simd, "endomorphism_split": bool(split),
+              "mads_per_mixed_addition": MADS_PER_ADD[group],
+              "sq_counters": "profiles/r3_sq_counters.json (rocprofv3 --pmc, tools/gpu_sq.sh): SQ_INSTS_VALU per launch / 1024 SIMDs x cycles = the same figure from the hardware's own count"}
         return rl, rv
 
     extras = {}
     cpu_baseline = cpu_all = None
     verified = None
+    clock_info = None                                        # in-kernel clock of the G1 accumulation (diagnostic build), headline run only
 
     # =============================================================== strong scaling: ONE problem split over the ranks (BASELINE config 5)
     if args.scaling == "strong":
@@ -608,6 +780,11 @@ def main():
     ex_elapsed = allmax(ex_elapsed)
     excl_ms = accum_stats()
 
+    if rank == 0 and not args.no_diag_clock and not args.precompute:
+        try:
+            clock_info = diag_clock_ghz(dev_index, d_bases_canon, n, d_s.data_ptr())
+        except Exception as e:                               # a diagnostic: never take the bench line down
+            print("bench.py: diagnostic clock leg failed: %r" % (e,), file=sys.stderr)
     # ---- untimed verification: sum over all ranks of (sum_i k_i s_i) * G must equal the folded result
     e_tot = gather_e(int(sum((to_ints(ks) * to_ints(ss)).tolist()) % R_MOD))
     if rank == 0:
@@ -668,7 +845,10 @@ def main():
             extras["roofline_ntt_2p22"] = {"bound": "hbm", "kernel": ("k_ntt29_pass" if f29 else "k_ntt_pass") + " (all passes of one forward transform)",
                                            "achieved": (1 << lg) * 64 / dtn / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": (1 << lg) * 64 / dtn / 1e9 / 8000.0,
                                            "passes": npass, "actual_bytes_moved": moved, "butterflies_on_29_bit_limbs": f29,
-                                           "valu_frac_of_mad_issue_peak": mads / dtn / VALU_PEAK_MADS,
+                                           "valu_mads_per_element": mads / (1 << lg),
+                                           "valu_frac_of_mad_issue_peak": (mads / 64.0 / N_SIMD * issue_costs()[0]["mad"]) / (dtn * (clock_info["ghz"] if clock_info else 2.1) * 1e9),
+                                           "valu_frac_note": "multiply-adds alone at the SIMD's issue cost (profiles/r3_ubench_issue.txt) over the transform's cycles at the clock "
+                                                             "the accumulation loop held in this run (the transform's own in-kernel clock is not stamped)",
                                            "note": "integer-VALU bound: 11 Fr products per element (22 stages as radix-4 steps); the mads alone are a third of the "
                                                    "instructions of a butterfly; see DESIGN.md 3.2"}
             del a
@@ -710,6 +890,10 @@ def main():
         if world == 1 and not args.no_prove:
             extras.update(bench_prove(ctx, v, cref, o, dev, torch, args.prove_log_n, precompute=True))
             extras.update(bench_prove_step_domain(ctx, v, cref, o, precompute=True))
+            try:
+                extras.update(bench_prove_small(ctx, v, cref, o, 16, precompute=True))
+            except Exception as e:                         # secondary measurement: never take the bench line down
+                extras["prove_2p16_error"] = repr(e)
 
     ctx.dfree(d_bases_canon)
     head.bases.free()
@@ -734,7 +918,8 @@ def main():
         c5["exchange_backend"] = exchange.backend
         c5["ranks_seen_by_collective"] = ranks_seen
 
-    rl, rv = roofline_of(1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
+    out_rl_inputs = (1, n, main_w, excl_ms, ex_elapsed / ex_steps * 1e3, pipe_ms, main_split)
+    rl, rv = roofline_of(*out_rl_inputs)
     out = {
         "metric": "G1 MSM points/sec at 2^20 (Groth16 prover hot path)",
         "value": n * world * args.steps / elapsed,

@@ -89,6 +89,10 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
  * multi-exponentiation -- a blocking read-back). */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
+/* Diagnostic build only (libvsp_hip_diag.so, `make -C vote_saver_protocol_amd/csrc diag`: the same sources with stamps around the G1
+ * accumulation loop -- in the shipped library no stamp executes and this returns VSP_ERR_UNSUPPORTED): the clock the chip held inside
+ * that loop since the last reset, delta s_memtime / delta s_memrealtime x 100 MHz summed over waves, and the number of waves. */
+int vsp_diag_clock(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out);
 
 /* ---- raw device memory helpers (for callers without torch) --------------------------------- */
 void *vsp_dmalloc(vsp_ctx *ctx, size_t bytes);
@@ -122,6 +126,8 @@ vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n)
  * Results are identical; sub-range calls (first, n) keep working. */
 int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits);
 size_t vsp_bases_count(const vsp_bases *b);
+/* device memory the handle holds: the Montgomery-form points (or the table of window multiples) plus the 28-bit-limb copy */
+size_t vsp_bases_device_bytes(const vsp_bases *b);
 void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b);
 
 /* MSM over resident bases [first, first+n) with scalars in DEVICE memory (n x 4 uint64, canonical).
@@ -243,6 +249,7 @@ const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp);
  * 4 L_query, 5 gamma_ABC_g1 (verification key), 6 alpha_g1, 7 beta_g1, 8 delta_g1, 9 beta_g2, 10 delta_g2, 11 gamma_g2,
  * 12 gamma_g1 (extended verification key: the SAVER key generation needs it). */
 size_t vsp_keypair_count(const vsp_keypair *kp, int which);
+size_t vsp_keypair_device_bytes(const vsp_keypair *kp);     /* device memory of the whole key (the six queries) */
 int vsp_keypair_export(vsp_ctx *ctx, const vsp_keypair *kp, int which, uint64_t *out);
 void vsp_keypair_free(vsp_ctx *ctx, vsp_keypair *kp);
 

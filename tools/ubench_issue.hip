@@ -20,7 +20,7 @@ static const char *NAMES[] = {"v_mad_u64_u32 (carry-out to an SGPR pair)", "v_ma
                               "v_mov_b32", "v_add_co_u32 + v_addc_co_u32", "v_lshl_add_u64", "v_add3_u32", "mm28 mix: 14 mad + 1 v_lshrrev_b64 + 1 v_and_b32"};
 static const int PER_ITER[] = {16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16, 16};
 
-struct Stamp { unsigned long long cyc, rt; unsigned hw, xcc; };
+struct Stamp { unsigned long long cyc, rt, t0, t1; unsigned hw, xcc; };
 
 template <int OP> __global__ __launch_bounds__(256) void kern(Stamp *out, uint32_t *sink, int iters) {
     uint32_t x = threadIdx.x * 2654435761u + 12345u, y = blockIdx.x * 40503u + 977u;
@@ -99,7 +99,7 @@ template <int OP> __global__ __launch_bounds__(256) void kern(Stamp *out, uint32
     sink[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32) ^ t;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-    if ((threadIdx.x & 63) == 0) { Stamp st; st.cyc = t1 - t0; st.rt = r1 - r0; st.hw = hw; st.xcc = xcc; out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = st; }
+    if ((threadIdx.x & 63) == 0) { Stamp st; st.cyc = t1 - t0; st.rt = r1 - r0; st.t0 = t0; st.t1 = t1; st.hw = hw; st.xcc = xcc; out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = st; }
 }
 
 template <int OP> int run(Stamp *d_st, uint32_t *d_sink, int cus) {
@@ -112,19 +112,25 @@ template <int OP> int run(Stamp *d_st, uint32_t *d_sink, int cus) {
         CHK(hipDeviceSynchronize());
         std::vector<Stamp> h(waves);
         CHK(hipMemcpy(h.data(), d_st, waves * sizeof(Stamp), hipMemcpyDeviceToHost));
-        // group the waves by the SIMD they ran on (HW_ID without the wave slot, plus the XCC): the placement is not always even, and a
-        // SIMD shared by n waves that each took c cycles per instruction issued one instruction per c / n cycles
-        std::map<unsigned long long, std::vector<double>> simd;
+        // group the waves by the SIMD they ran on (XCC, SE, SH, CU, SIMD of HW_ID).  The SIMD's issue cost is what it took the SIMD to get
+        // through ALL its waves' instructions: (last wave's end - first wave's start) / instructions of all its waves.  (A wave's own
+        // average is NOT that: the waves of a SIMD do not progress at equal speed -- the arbiter favours one, which then leaves early and
+        // the others speed up -- so per-wave medians divided by the wave count under-state the cost by up to 2x; the first version of
+        // this tool and the per-wave reading of ubench_madd28 made that mistake.)
+        struct Acc { unsigned long long t0 = ~0ull, t1 = 0; size_t n = 0; double lone = 0; };
+        std::map<unsigned long long, Acc> simd;
         std::vector<double> ghz(waves);
         for (int i = 0; i < waves; i++) {
-            simd[((unsigned long long)(h[i].xcc & 0xF) << 32) | ((h[i].hw >> 4) & 0x3u) | (((h[i].hw >> 8) & 0xFFu) << 2)]      /* SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13] */.push_back((double)h[i].cyc / ((double)iters * PER_ITER[OP]));
+            Acc &a = simd[((unsigned long long)(h[i].xcc & 0xF) << 32) | ((h[i].hw >> 4) & 0x3u) | (((h[i].hw >> 8) & 0xFFu) << 2)];
+            a.t0 = std::min(a.t0, h[i].t0); a.t1 = std::max(a.t1, h[i].t1); a.n++;
+            a.lone = std::max(a.lone, (double)h[i].cyc / ((double)iters * PER_ITER[OP]));
             ghz[i] = h[i].rt ? (double)h[i].cyc / (double)h[i].rt * 0.1 : 0.0;
         }
         std::sort(ghz.begin(), ghz.end());
-        std::map<size_t, std::vector<double>> by_n;               // waves sharing the SIMD -> per-SIMD issue cost of those SIMDs
-        for (auto &kv : simd) { double m = 0; for (double c : kv.second) m += c; m /= kv.second.size(); by_n[kv.second.size()].push_back(m / kv.second.size()); }
-        printf("%-52s %d wave/SIMD asked (clock held %.2f GHz, %zu SIMDs seen):", NAMES[OP], wps, ghz[waves / 2], simd.size());
-        for (auto &kv : by_n) { std::vector<double> &v = kv.second; std::sort(v.begin(), v.end()); printf("  [%zu SIMDs with %zu waves: %.2f cycles per wave-instruction]", v.size(), kv.first, v[v.size() / 2]); }
+        std::map<size_t, std::vector<double>> by_n;               // waves sharing the SIMD -> cycles of that SIMD per wave-instruction
+        for (auto &kv : simd) by_n[kv.second.n].push_back((double)(kv.second.t1 - kv.second.t0) / ((double)kv.second.n * iters * PER_ITER[OP]));
+        printf("%-52s %d wave/SIMD (clock held %.2f GHz):", NAMES[OP], wps, ghz[waves / 2]);
+        for (auto &kv : by_n) { std::vector<double> &v = kv.second; std::sort(v.begin(), v.end()); printf("  [%zu SIMDs with %zu waves: %.2f cycles of the SIMD per wave-instruction]", v.size(), kv.first, v[v.size() / 2]); }
         printf("\n");
     }
     return 0;

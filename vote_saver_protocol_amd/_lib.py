@@ -25,6 +25,7 @@ PROTOTYPES = {
     "vsp_get_stat": (C.c_double, [_P, C.c_char_p]),
     "vsp_stats_reset": (None, [_P]),
     "vsp_set_option": (_I, [_P, C.c_char_p, C.c_long]),
+    "vsp_diag_clock": (_I, [_P, _I, _P, _P]),
     "vsp_dmalloc": (_P, [_P, _SZ]),
     "vsp_dfree": (None, [_P, _P]),
     "vsp_h2d": (_I, [_P, _P, _P, _SZ]),
@@ -39,6 +40,8 @@ PROTOTYPES = {
     "vsp_bases_from_device_g2": (_P, [_P, _P, _SZ]),
     "vsp_bases_precompute": (_I, [_P, _P, _U]),
     "vsp_bases_count": (_SZ, [_P]),
+    "vsp_bases_device_bytes": (_SZ, [_P]),
+    "vsp_keypair_device_bytes": (_SZ, [_P]),
     "vsp_bases_free": (None, [_P, _P]),
     "vsp_msm_resident": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P]),
     "vsp_msm_resident_jacobian": (_I, [_P, _P, _SZ, _SZ, _P, _P]),

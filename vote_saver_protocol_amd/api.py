@@ -425,6 +425,10 @@ class Keypair:
         self.ctx.check(self.ctx.lib.vsp_pk_to_blob(self.ctx.h, self.h, _ptr(out)))
         return out.tobytes()
 
+    def device_bytes(self):
+        """device memory the key's six queries hold (points, tables of window multiples, 28-bit-limb copies)"""
+        return self.ctx.lib.vsp_keypair_device_bytes(self.h)
+
     def part(self, name):
         which, width = KEY_PARTS[name]
         n = self.ctx.lib.vsp_keypair_count(self.h, which)

@@ -164,6 +164,11 @@ double vsp_get_stat(vsp_ctx *ctx, const char *name) {
     return it == ctx->stats.end() ? 0.0 : it->second;
 }
 void vsp_stats_reset(vsp_ctx *ctx) { if (ctx) ctx->stats.clear(); }
+int vsp_diag_clock(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    VSP_HIP(hipSetDevice(ctx->device));
+    return msm_diag_clock(ctx, reset, ghz_out, waves_out);
+}
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value) {
     if (!ctx || !name) return VSP_ERR_ARG;
     ctx->opts[name] = value;
@@ -368,6 +373,12 @@ vsp_bases *vsp_bases_upload_g2(vsp_ctx *ctx, const uint64_t *bases, size_t n) { 
 vsp_bases *vsp_bases_from_device_g1(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_create(ctx, 1, d_bases, true, n, BASES_CALLER); }
 vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n) { return bases_create(ctx, 2, d_bases, true, n, BASES_CALLER); }
 size_t vsp_bases_count(const vsp_bases *b) { return b ? b->n : 0; }
+size_t vsp_bases_device_bytes(const vsp_bases *b) {
+    if (!b) return 0;
+    const size_t slices = b->pre_c ? 255 / b->pre_c + 1 : 1, count = b->n * slices;
+    const size_t esz = b->group == 1 ? sizeof(G1Affine) : sizeof(G2Affine), row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
+    return (count ? count * esz : 16) + (b->d28 ? count * row * (b->glv ? 2 : 1) : 0);
+}
 void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }

@@ -222,6 +222,7 @@ int bases_to_mont_g1(vsp_ctx *ctx, const void *d_canon, G1Affine *d_out, size_t 
 int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t n, int check_curve, uint32_t *d_flag);
 // raises bit 2 of *d_flag when some point fails phi(P) = lambda P (the endomorphism split's precondition; msm_impl.inc k_subgroup_check)
 int subgroup_check_g1(vsp_ctx *ctx, const G1Affine *d_mont, size_t n, uint32_t *d_flag);
+int msm_diag_clock(vsp_ctx *ctx, int reset, double *ghz, double *waves);
 int subgroup_check_g2(vsp_ctx *ctx, const G2Affine *d_mont, size_t n, uint32_t *d_flag);
 // resident bases from canonical points; trust: BASES_CALLER = caller data (validated; the split only after the subgroup check),
 // BASES_OWN = points this library computed as multiples of a generator (in the subgroup by construction: no check),

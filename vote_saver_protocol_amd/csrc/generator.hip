@@ -160,6 +160,11 @@ const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp) { return kp ? kp->pk : nullp
 
 // which: 0 A_query, 1 B_query_g1, 2 B_query_g2, 3 H_query, 4 L_query, 5 gamma_ABC_g1, 6 alpha_g1, 7 beta_g1, 8 delta_g1,
 //        9 beta_g2, 10 delta_g2, 11 gamma_g2, 12 gamma_g1
+size_t vsp_keypair_device_bytes(const vsp_keypair *kp) {
+    size_t t = 0;
+    if (kp) for (int i = 0; i < 6; i++) t += vsp_bases_device_bytes(kp->q[i]);
+    return t;
+}
 size_t vsp_keypair_count(const vsp_keypair *kp, int which) {
     if (!kp || which < 0 || which > 12) return 0;
     return which < 6 ? (kp->q[which] ? kp->q[which]->n : 0) : 1;       // a key loaded from a proving-key blob has no gamma_ABC_g1
