@@ -77,6 +77,23 @@ def test_cpp_shims_compile_and_link(tmp_path):
     assert os.path.exists(exe)
 
 
+def test_upstream_shaped_prover_unit_compiles_with_only_an_include_path_change(tmp_path):
+    """A libsnark-shaped prover translation unit written against upstream's include paths and namespaces (tests/cpu_build/prover_loop.cpp
+    names nothing of this repository) compiles and links once include/overlay is on the include path; the value types come from a
+    stand-in with crypto3's member shapes (.data, .data[0].data, X / Y / Z, to_affine(): bin/cli/include/nil/vote_saver/common.hpp:92-129)."""
+    import subprocess
+    src = open(os.path.join(ROOT, "tests", "cpu_build", "prover_loop.cpp")).read()
+    code = re.sub(r"//.*", "", src)
+    assert "vsp" not in code and "#include <nil/crypto3/algebra/multiexp/multiexp.hpp>" in src
+    exe = str(tmp_path / "prover_loop")
+    libdir = os.path.join(ROOT, "vote_saver_protocol_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include", "overlay"), "-I", os.path.join(ROOT, "tests", "cpu_build", "standin"),
+                           os.path.join(ROOT, "tests", "cpu_build", "prover_loop.cpp"), "-o", exe, "-L", libdir, "-lvsp_hip", "-Wl,-rpath," + libdir])
+    for hdr in ("algebra/multiexp/multiexp.hpp", "algebra/multiexp/policies.hpp", "math/domains/evaluation_domain.hpp", "math/domains/basic_radix2_domain.hpp",
+                "math/domains/step_radix2_domain.hpp", "math/algorithms/make_evaluation_domain.hpp", "zk/commitments/detail/polynomial/knowledge_commitment_multiexp.hpp"):
+        assert os.path.exists(os.path.join(ROOT, "include", "overlay", "nil", "crypto3", hdr)), hdr
+
+
 def test_wire_format_round_trip_of_reference_proof():
     """Host-only entry points (no GPU): the library decompresses the reference's data.bin proof (A | B | C) to the points the Python
     oracle decodes, recompresses them to the same bytes, and rejects malformed encodings."""
