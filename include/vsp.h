@@ -236,6 +236,27 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
                       const uint64_t *saver_P1 /* 12 or NULL */, const uint64_t *saver_r_enc /* 4 or NULL */,
                       uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
 
+/* The same proof in two halves, so that ONE host thread keeps several proofs in flight over one resident key -- one per context:
+ *     vsp_groth16_prove_launch(ctxA, ...); vsp_groth16_prove_launch(ctxB, ...); vsp_groth16_prove_finish(ctxA, ...); launch(ctxA, next) ...
+ * launch queues every kernel of the proof on the context's streams and returns (it copies r, s and the SAVER term; a witness in
+ * page-locked memory, vsp_host_register, must stay unchanged until the finish -- pageable memory is copied before launch returns);
+ * finish does the host-side scalar multiplications, waits for the GPU and assembles the proof.  One proof in flight per context. */
+int vsp_groth16_prove_launch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4],
+                             const uint64_t *saver_P1 /* 12 or NULL */, const uint64_t *saver_r_enc /* 4 or NULL */);
+int vsp_groth16_prove_finish(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
+/* Packed witness: a Groth16 witness is mostly wires equal to 0 or 1, and its 32 bytes per wire cross PCIe in front of every proof with the
+ * GPU idle (0.8 ms at 2^20 constraints).  Packed form: class_words = two bits per wire (0 = zero, 1 = one, 2 = a dense value; 3 reserved),
+ * 32 wires per uint64, (num_vars + 31) / 32 words; word_offsets[w] = the index, among the dense values, of word w's first one; dense = the
+ * dense values in wire order, 4 canonical words each.  A witness generator can emit this form directly (the reference builds its witness
+ * wire by wire, common.hpp:1110-1128); vsp_witness_pack converts a plain witness in one host pass.  The launch validates the map
+ * against n_dense and expands it on the GPU; everything else is vsp_groth16_prove_launch. */
+size_t vsp_witness_pack_words(size_t num_vars);
+int vsp_witness_pack(const uint64_t *witness, size_t num_vars, uint64_t *class_words, uint32_t *word_offsets, uint64_t *dense_out /* or NULL: count only */,
+                     size_t dense_capacity, size_t *n_dense_out);
+int vsp_groth16_prove_launch_packed(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *class_words, const uint32_t *word_offsets,
+                                    const uint64_t *dense, size_t n_dense, const uint64_t r[4], const uint64_t s[4],
+                                    const uint64_t *saver_P1, const uint64_t *saver_r_enc);
+
 /* ---- Groth16 generator: zk::generate<proof_system>(constraint_system), bin/cli/.../common.hpp:916-917 ----
  * r1cs_gg_ppzksnark_generator with explicit toxic waste toxic[20] = (t, alpha, beta, gamma, delta), 4 limbs each, canonical
  * (upstream draws them from algebraic_random_device).  Builds the whole key on the GPU: Lagrange coefficients at t, the

@@ -151,3 +151,29 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode in (0, 77), r.stdout + r.stderr
     assert "generator round trip ok, first byte 97" in r.stdout
+
+
+def test_witness_pack_is_host_only_and_exact():
+    """vsp_witness_pack: two class bits per wire (0, 1, dense), per-word offsets of the dense values, the dense values in wire order"""
+    import ctypes as C
+    lib = v.load()
+    rng = np.random.default_rng(9)
+    n = 1000 + 7
+    wit = np.zeros((n, 4), np.uint64)
+    kind = rng.integers(0, 10, n)
+    wit[kind == 1, 0] = 1
+    dense_rows = np.nonzero(kind >= 8)[0]
+    wit[dense_rows] = rng.integers(2, 1 << 62, size=(len(dense_rows), 4), dtype=np.uint64)
+    wit[dense_rows[0]] = [0, 0, 0, 1]                           # zero low word, non-zero high word: dense, not "zero"
+    wit[dense_rows[1]] = [1, 5, 0, 0]                           # low word one, more above: dense, not "one"
+    pw = v.PackedWitness(wit)
+    assert pw.n_dense == len(dense_rows) and np.array_equal(pw.dense[:pw.n_dense], wit[dense_rows])
+    assert len(pw.class_words) == lib.vsp_witness_pack_words(n) == (n + 31) // 32
+    k = 0
+    for i in range(n):
+        cls = (int(pw.class_words[i // 32]) >> (2 * (i % 32))) & 3
+        assert cls == (2 if kind[i] >= 8 else (1 if kind[i] == 1 else 0))
+        if i % 32 == 0:
+            assert pw.word_offsets[i // 32] == k
+        k += cls == 2
+    assert int(pw.class_words[-1]) >> (2 * (n % 32)) == 0        # nothing beyond the last wire

@@ -178,3 +178,61 @@ def test_generate_and_prove_2p20_config4_pairing(ctx, cref):
     qa, qb, qc, proof2 = v.groth16_prove(ctx, dcs, kp2.pk, wit, r, s)
     assert np.array_equal(qa, pa) and np.array_equal(qb, pb) and np.array_equal(qc, pc) and proof2 == proof
     kp2.free(); dcs.free(); cs.free()
+
+
+def test_prove_in_two_halves_and_from_a_packed_witness(cref):
+    """vsp_groth16_prove_launch / _finish (one host thread, several proofs in flight, one per context) and the packed witness
+    (two class bits per wire + the dense values, expanded on the GPU) give the proof of vsp_groth16_prove, bit for bit; malformed
+    packed maps and out-of-order calls are refused."""
+    import ctypes as C
+    with v.Context(0) as c1, v.Context(0) as c2, v.Context(0) as c3:
+        cs, wit, kp, dcs, pk, q, r, s = build(c1, cref, 3000, 7, seed=808, precompute="all")
+        ref = v.groth16_prove(c1, dcs, pk, wit, r, s)
+        eA, eB, eC = kp.prove(wit, r, s)
+        assert np.array_equal(ref[0], eA) and np.array_equal(ref[1], eB) and np.array_equal(ref[2], eC)
+        pw = v.PackedWitness(wit)
+        assert 0 < pw.n_dense < wit.shape[0] and pw.nbytes < wit.nbytes // 2          # the synthetic witness is 90 % boolean
+        # one thread, three contexts over ONE key and constraint system: launch all, finish in order, twice around; plain and packed alternate
+        ctxs = (c1, c2, c3)
+        for c in ctxs[1:]:
+            v.groth16_prove(c, dcs, pk, wit, r, s)                                     # first use: workspaces
+        for rounds in range(2):
+            for k, c in enumerate(ctxs):
+                v.groth16_prove_launch(c, dcs, pk, pw if (k + rounds) & 1 else wit, r, s)
+            for c in ctxs:
+                got = v.groth16_prove_finish(c)
+                assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3]
+        # the SAVER term travels through the launch
+        P1 = kp.part("A_query")[3]; renc = L(987654321, 4)
+        want = v.groth16_prove(c1, dcs, pk, wit, r, s, saver_P1=P1, saver_r_enc=renc)
+        v.groth16_prove_launch(c2, dcs, pk, pw, r, s, saver_P1=P1, saver_r_enc=renc)
+        assert v.groth16_prove_finish(c2)[3] == want[3] != ref[3]
+        # out-of-order calls
+        with pytest.raises(v.VspError, match="no proof in flight"):
+            v.groth16_prove_finish(c1)
+        v.groth16_prove_launch(c1, dcs, pk, wit, r, s)
+        with pytest.raises(v.VspError, match="already in flight"):
+            v.groth16_prove_launch(c1, dcs, pk, wit, r, s)
+        assert v.groth16_prove_finish(c1)[3] == ref[3]
+        # malformed packed witnesses: an offset off by one, a dense count that does not match, the reserved class, bits beyond num_vars
+        for damage in ("offset", "count", "class3", "tail"):
+            bad = v.PackedWitness(wit)
+            if damage == "offset":
+                bad.word_offsets[len(bad.word_offsets) // 2] += 1
+            elif damage == "count":
+                bad.n_dense -= 1
+            elif damage == "class3":
+                bad.class_words[1] |= np.uint64(3)
+            else:
+                assert wit.shape[0] % 32                                               # 3007 wires: the last word is partly used
+                bad.class_words[-1] |= np.uint64(1) << np.uint64(62)
+            with pytest.raises(v.VspError, match="packed witness"):
+                v.groth16_prove_launch(c1, dcs, pk, bad, r, s)
+        assert v.groth16_prove(c1, dcs, pk, wit, r, s)[3] == ref[3]                    # the context is usable after the refusals
+        # a scalar >= r among the dense values is caught where the plain witness's would be (the census of the multi-exponentiations)
+        bad = v.PackedWitness(wit); bad.dense[0] = L(o.R, 4)
+        v.groth16_prove_launch(c1, dcs, pk, bad, r, s)
+        with pytest.raises(v.VspError, match="canonical"):
+            v.groth16_prove_finish(c1)
+        assert v.groth16_prove(c1, dcs, pk, wit, r, s)[3] == ref[3]
+        pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

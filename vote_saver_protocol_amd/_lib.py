@@ -73,6 +73,11 @@ PROTOTYPES = {
     "vsp_pk_create": (_P, [_P] * 11),
     "vsp_pk_free": (None, [_P, _P]),
     "vsp_groth16_prove": (_I, [_P] * 12),
+    "vsp_groth16_prove_launch": (_I, [_P] * 8),
+    "vsp_groth16_prove_finish": (_I, [_P] * 5),
+    "vsp_witness_pack_words": (_SZ, [_SZ]),
+    "vsp_witness_pack": (_I, [_P, _SZ, _P, _P, _P, _SZ, _P]),
+    "vsp_groth16_prove_launch_packed": (_I, [_P, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _P]),
     "vsp_groth16_generate": (_P, [_P, _P, _P, _I]),
     "vsp_keypair_pk": (_P, [_P]),
     "vsp_keypair_count": (_SZ, [_P, _I]),

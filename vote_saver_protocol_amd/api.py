@@ -461,6 +461,54 @@ def groth16_prove(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
     return A, B, Cc, proof.tobytes()
 
 
+class PackedWitness:
+    """the witness in the packed form of vsp_witness_pack: two class bits per wire, per-word offsets, the dense values"""
+
+    def __init__(self, witness):
+        witness = _u64(witness, 4)
+        lib = _lib.load()
+        self.num_vars = witness.shape[0]
+        words = lib.vsp_witness_pack_words(self.num_vars)
+        self.class_words = np.zeros(words, np.uint64); self.word_offsets = np.zeros(words, np.uint32)
+        n = C.c_size_t(0)
+        if lib.vsp_witness_pack(_ptr(witness), self.num_vars, _ptr(self.class_words), _ptr(self.word_offsets), None, 0, C.byref(n)) != 0:
+            raise ValueError("witness_pack failed")
+        self.dense = np.zeros((max(n.value, 1), 4), np.uint64)
+        if lib.vsp_witness_pack(_ptr(witness), self.num_vars, _ptr(self.class_words), _ptr(self.word_offsets), _ptr(self.dense), n.value, C.byref(n)) != 0:
+            raise ValueError("witness_pack failed")
+        self.n_dense = n.value
+
+    @property
+    def nbytes(self):
+        return self.class_words.nbytes + self.word_offsets.nbytes + self.n_dense * 32
+
+
+def groth16_prove_launch(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
+    """first half of groth16_prove: queue the whole proof on the context's streams and return (one proof in flight per context).
+    witness: an array [num_vars, 4] (keep it alive and unchanged until the finish when it is page-locked) or a PackedWitness."""
+    p1 = None if saver_P1 is None else _u64(saver_P1)
+    re = None if saver_r_enc is None else _u64(saver_r_enc)
+    r, s = _u64(r), _u64(s)
+    if isinstance(witness, PackedWitness):
+        if witness.num_vars != cs.num_vars:
+            raise ValueError("prove: witness must have num_vars entries (primary || auxiliary)")
+        ctx.check(ctx.lib.vsp_groth16_prove_launch_packed(ctx.h, cs.h, pk.h, _ptr(witness.class_words), _ptr(witness.word_offsets), _ptr(witness.dense),
+                                                          witness.n_dense, _ptr(r), _ptr(s), _ptr(p1), _ptr(re)))
+        return
+    witness = _u64(witness, 4)
+    if witness.shape[0] != cs.num_vars:
+        raise ValueError("prove: witness must have num_vars entries (primary || auxiliary)")
+    ctx.check(ctx.lib.vsp_groth16_prove_launch(ctx.h, cs.h, pk.h, _ptr(witness), _ptr(r), _ptr(s), _ptr(p1), _ptr(re)))
+
+
+def groth16_prove_finish(ctx):
+    """second half: host-side assembly work, the wait, the proof.  -> (A[12], B[24], C[12], proof_bytes[192])"""
+    A = np.zeros(12, np.uint64); B = np.zeros(24, np.uint64); Cc = np.zeros(12, np.uint64)
+    proof = np.zeros(192, np.uint8)
+    ctx.check(ctx.lib.vsp_groth16_prove_finish(ctx.h, _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
+    return A, B, Cc, proof.tobytes()
+
+
 # ---- SAVER wrapper (f.3): elgamal_verifiable over BLS12-381 around the prover ---------------------------------------------
 def saver_generate_keypair(ctx, rnd, gamma_abc_g1, delta_g1, gamma_g1, msg_size):
     """generate_keypair<elgamal_verifiable>(rnd, {gg_keypair, msg_size}) (common.hpp:921-931) with the 3 * msg_size + 2 random scalars

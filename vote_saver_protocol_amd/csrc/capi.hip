@@ -125,6 +125,12 @@ vsp_ctx *vsp_create(int device_ordinal) {
     ctx->stream = ctx->own_stream;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
+    // The prover's two witness chains get their streams NOW, ahead of every work slot's: the runtime deals its hardware queues (4 per
+    // priority unless GPU_MAX_HW_QUEUES says otherwise) to streams in creation order, and two chains that land on one queue run one after
+    // the other (7.4 instead of 6.6 ms per proof in a process with a dozen streams).  Created first, they get a queue each whatever else
+    // the process creates later -- the library does not depend on that environment variable.
+    for (int k = 0; k < 2; k++) if (msm_make_slot_stream(ctx, &ctx->prove_streams[k]) != VSP_OK) ctx->prove_streams[k] = nullptr;
+    ctx->err.clear();
     return ctx;
 }
 
@@ -135,7 +141,7 @@ void vsp_destroy(vsp_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch, &ctx->dom_scratch,
                       &ctx->ntt.fwd29, &ctx->ntt.inv29, &ctx->ntt.pw29[0], &ctx->ntt.pw29[1], &ctx->ntt.pw29[2], &ctx->ntt.pw29[3],
                       &ctx->msm_scalars, &ctx->val_flag, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
-                      &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h};
+                      &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h, &ctx->pr_pack};
     for (DevBuf *b : bufs) free_buf(*b);
     msm_free_slots(ctx);
     if (ctx->h_fold) hipHostFree(ctx->h_fold);

@@ -109,7 +109,9 @@ struct vsp_ctx {
     // fixed-base tables (generator multiples), built lazily
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
     // prover workspaces
-    vsp::DevBuf pr_z, pr_a, pr_b, pr_c, pr_h;
+    vsp::DevBuf pr_z, pr_a, pr_b, pr_c, pr_h, pr_pack;
+    // a proof in flight between vsp_groth16_prove_launch and _finish (one per context)
+    struct { bool active = false; const vsp_pk *pk = nullptr; uint64_t r[4], s[4], P1[12], r_enc[4]; bool has_saver = false; } prove;
 };
 
 struct vsp_bases {

@@ -129,22 +129,15 @@ vsp_pk *vsp_pk_create(vsp_ctx *ctx, const uint64_t alpha_g1[12], const uint64_t 
 }
 void vsp_pk_free(vsp_ctx *, vsp_pk *pk) { delete pk; }
 
-static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
-                        const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
-                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap);
+// the witness as the caller hands it over: plain (num_vars x 4 canonical words), or packed (vsp_witness_pack)
+struct WitnessSrc { const uint64_t *plain; const uint64_t *class_words; const uint32_t *word_offsets; const uint64_t *dense; size_t n_dense; };
+static int prove_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const WitnessSrc &w, const uint64_t r[4], const uint64_t s[4],
+                             const uint64_t *saver_P1, const uint64_t *saver_r_enc);
+static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap);
 
 }  // extern "C"
 namespace vsp {
-// the prover with a hook: `overlap` runs on the host after every kernel is queued and before the first wait -- the window in which
-// the host has nothing to do but wait for the GPU (vsp_saver_encrypt computes its ciphertext there)
-int prove_with_overlap(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4],
-                       const uint64_t *saver_P1, const uint64_t *saver_r_enc, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12],
-                       uint8_t proof_out[192], const std::function<void()> *overlap) {
-    if (!ctx) return VSP_ERR_ARG;
-    if (!cs || !pk || !witness || !r || !s) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
-    if (!fr_canonical(r) || !fr_canonical(s) || (saver_r_enc && !fr_canonical(saver_r_enc)))
-        return set_error(ctx, VSP_ERR_ARG, "prove: r, s and r_enc must be canonical (< r)");
-    int rc = prove_queued(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out, overlap);
+static void prove_cleanup(vsp_ctx *ctx, int rc) {
     if (rc != VSP_OK) {
         // an early return leaves multi-exponentiations in flight on their own streams, still reading the witness and H vectors:
         // wait for all of them before the caller (or the next call's workspace growth) can touch those buffers
@@ -155,6 +148,29 @@ int prove_with_overlap(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const
     for (unsigned k = 1; k <= 4; k++) (void)msm_slot_use_stream(ctx, k, nullptr);      // the slots go back to their own streams
     // the witness does not outlive the call in device memory
     if (ctx->pr_z.p) hipMemsetAsync(ctx->pr_z.p, 0, ctx->pr_z.cap, ctx->stream);
+    ctx->prove.active = false;
+}
+static int prove_launch_checked(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const WitnessSrc &w, const uint64_t r[4], const uint64_t s[4],
+                                const uint64_t *saver_P1, const uint64_t *saver_r_enc) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!cs || !pk || !r || !s || (!w.plain && !(w.class_words && w.word_offsets && (w.dense || !w.n_dense)))) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
+    if (ctx->prove.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
+    if (!fr_canonical(r) || !fr_canonical(s) || (saver_r_enc && !fr_canonical(saver_r_enc)))
+        return set_error(ctx, VSP_ERR_ARG, "prove: r, s and r_enc must be canonical (< r)");
+    int rc = prove_launch_impl(ctx, cs, pk, w, r, s, saver_P1, saver_r_enc);
+    if (rc != VSP_OK) prove_cleanup(ctx, rc);
+    return rc;
+}
+// the prover with a hook: `overlap` runs on the host after every kernel is queued and before the first wait -- the window in which
+// the host has nothing to do but wait for the GPU (vsp_saver_encrypt computes its ciphertext there)
+int prove_with_overlap(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4],
+                       const uint64_t *saver_P1, const uint64_t *saver_r_enc, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12],
+                       uint8_t proof_out[192], const std::function<void()> *overlap) {
+    WitnessSrc w{witness, nullptr, nullptr, nullptr, 0};
+    int rc = prove_launch_checked(ctx, cs, pk, w, r, s, saver_P1, saver_r_enc);
+    if (rc != VSP_OK) return rc;
+    rc = prove_finish_impl(ctx, A_out, B_out, C_out, proof_out, overlap);
+    prove_cleanup(ctx, rc);
     return rc;
 }
 }  // namespace vsp
@@ -165,10 +181,88 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
                       uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
     return prove_with_overlap(ctx, cs, pk, witness, r, s, saver_P1, saver_r_enc, A_out, B_out, C_out, proof_out, nullptr);
 }
+// The same call in two halves, so that ONE host thread keeps several proofs in flight (one per context, all over one resident key): launch
+// queues every kernel of the proof and returns; finish does the host-side scalar multiplications, waits and assembles.
+int vsp_groth16_prove_launch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness, const uint64_t r[4], const uint64_t s[4],
+                             const uint64_t *saver_P1, const uint64_t *saver_r_enc) {
+    WitnessSrc w{witness, nullptr, nullptr, nullptr, 0};
+    return prove_launch_checked(ctx, cs, pk, w, r, s, saver_P1, saver_r_enc);
+}
+int vsp_groth16_prove_launch_packed(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *class_words, const uint32_t *word_offsets,
+                                    const uint64_t *dense, size_t n_dense, const uint64_t r[4], const uint64_t s[4],
+                                    const uint64_t *saver_P1, const uint64_t *saver_r_enc) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!cs || !class_words || !word_offsets || (!dense && n_dense)) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
+    // the class map indexes the dense values on the device: refuse a map whose offsets or count do not add up (a read outside the buffer)
+    {
+        const size_t nv = cs->num_vars, words = (nv + 31) / 32;
+        size_t run = 0;
+        for (size_t wd = 0; wd < words; wd++) {
+            uint64_t cw = class_words[wd];
+            if (wd == words - 1 && (nv & 31) && (cw >> (2 * (nv & 31)))) return set_error(ctx, VSP_ERR_ARG, "prove: packed witness has class bits beyond num_vars");
+            if ((cw >> 1) & cw & 0x5555555555555555ull) return set_error(ctx, VSP_ERR_ARG, "prove: packed witness uses the reserved class 3");
+            if (word_offsets[wd] != run) return set_error(ctx, VSP_ERR_ARG, "prove: packed witness offsets do not match its class map");
+            run += (size_t)__builtin_popcountll((cw >> 1) & 0x5555555555555555ull);
+        }
+        if (run != n_dense) return set_error(ctx, VSP_ERR_ARG, "prove: packed witness dense count does not match its class map");
+    }
+    WitnessSrc w{nullptr, class_words, word_offsets, dense, n_dense};
+    return prove_launch_checked(ctx, cs, pk, w, r, s, saver_P1, saver_r_enc);
+}
+int vsp_groth16_prove_finish(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!ctx->prove.active) return set_error(ctx, VSP_ERR_ARG, "prove_finish: no proof in flight on this context");
+    int rc = prove_finish_impl(ctx, A_out, B_out, C_out, proof_out, nullptr);
+    prove_cleanup(ctx, rc);
+    return rc;
+}
+// Packed witness.  A Groth16 witness is mostly wires equal to 0 or 1, and its 32 bytes per wire cross PCIe in front of every proof with
+// the GPU idle (0.8 ms at 2^20 constraints).  Packed form: two bits per wire (0 = zero, 1 = one, 2 = a dense value), 32 wires per 64-bit
+// word; per word the index of its first dense value; the dense values (4 words each) in wire order.  A witness generator can emit this
+// directly; vsp_witness_pack converts a plain witness (one pass over it on the host).  Sizes: words = (n + 31) / 32.
+size_t vsp_witness_pack_words(size_t n) { return (n + 31) / 32; }
+int vsp_witness_pack(const uint64_t *witness, size_t n, uint64_t *class_words, uint32_t *word_offsets, uint64_t *dense_out, size_t dense_capacity, size_t *n_dense_out) {
+    if ((!witness && n) || !class_words || !word_offsets || !n_dense_out) return VSP_ERR_ARG;
+    size_t nd = 0;
+    const size_t words = (n + 31) / 32;
+    for (size_t wd = 0; wd < words; wd++) {
+        uint64_t cw = 0;
+        word_offsets[wd] = (uint32_t)nd;
+        const size_t lim = n - 32 * wd < 32 ? n - 32 * wd : 32;
+        for (size_t j = 0; j < lim; j++) {
+            const uint64_t *v = witness + 4 * (32 * wd + j);
+            const bool small = (v[1] | v[2] | v[3]) == 0 && v[0] <= 1;
+            if (small) cw |= (uint64_t)v[0] << (2 * j);
+            else {
+                cw |= (uint64_t)2 << (2 * j);
+                if (dense_out) { if (nd >= dense_capacity) return VSP_ERR_ARG; memcpy(dense_out + 4 * nd, v, 32); }
+                nd++;
+            }
+        }
+        class_words[wd] = cw;
+    }
+    *n_dense_out = nd;
+    return nd > 0xFFFFFFFFull ? VSP_ERR_UNSUPPORTED : VSP_OK;
+}
 
-static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witness,
-                        const uint64_t r[4], const uint64_t s[4], const uint64_t *saver_P1, const uint64_t *saver_r_enc,
-                        uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap) {
+// z[1 + i] of the packed witness: 0, 1 or the next dense value (canonical words either way)
+__global__ __launch_bounds__(256) void k_witness_expand(const uint64_t *class_words, const uint32_t *word_offsets, const uint4 *dense, size_t n, uint4 *z) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t cw = class_words[i >> 5];
+    const unsigned j = (unsigned)(i & 31), cls = (unsigned)(cw >> (2 * j)) & 3u;
+    uint4 lo = make_uint4(cls == 1 ? 1u : 0u, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+    if (cls >= 2) {
+        // dense values before this wire inside the word: the even bits of the class pairs above... class 2 = binary 10: count the high bits below j
+        const uint64_t highs = (cw >> 1) & 0x5555555555555555ull & ((j ? ((uint64_t)1 << (2 * j)) : 1ull) - 1ull);
+        const size_t k = (size_t)word_offsets[i >> 5] + (size_t)__popcll(highs);
+        lo = dense[2 * k]; hi = dense[2 * k + 1];
+    }
+    z[2 * i] = lo; z[2 * i + 1] = hi;
+}
+
+static int prove_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const WitnessSrc &wsrc, const uint64_t r[4], const uint64_t s[4],
+                             const uint64_t *saver_P1, const uint64_t *saver_r_enc) {
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints;
     const size_t m = cs->dom.m;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
@@ -187,7 +281,19 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
     Fr *dz = (Fr *)ctx->pr_z.p, *dA = (Fr *)ctx->pr_a.p, *dB = (Fr *)ctx->pr_b.p, *dC = (Fr *)ctx->pr_c.p, *dH = (Fr *)ctx->pr_h.p;
     const uint64_t one4[4] = {1, 0, 0, 0};
     VSP_HIP(hipMemcpyAsync(dz, one4, 32, hipMemcpyHostToDevice, st));
-    VSP_HIP(hipMemcpyAsync(dz + 1, witness, nv * 32, hipMemcpyHostToDevice, st));
+    if (wsrc.plain) VSP_HIP(hipMemcpyAsync(dz + 1, wsrc.plain, nv * 32, hipMemcpyHostToDevice, st));
+    else {
+        // packed witness: class map, per-word offsets and the dense values cross PCIe (a tenth of the plain witness for a 90 % boolean one); a kernel expands
+        const size_t words = (nv + 31) / 32;
+        VSP_TRY(ensure(ctx, ctx->pr_pack, words * 12 + wsrc.n_dense * 32 + 64));
+        uint64_t *d_cw = (uint64_t *)ctx->pr_pack.p; uint32_t *d_off = (uint32_t *)(d_cw + words);
+        uint4 *d_dense = (uint4 *)(((uintptr_t)(d_off + words) + 15) & ~(uintptr_t)15);
+        VSP_HIP(hipMemcpyAsync(d_cw, wsrc.class_words, words * 8, hipMemcpyHostToDevice, st));
+        VSP_HIP(hipMemcpyAsync(d_off, wsrc.word_offsets, words * 4, hipMemcpyHostToDevice, st));
+        if (wsrc.n_dense) VSP_HIP(hipMemcpyAsync(d_dense, wsrc.dense, wsrc.n_dense * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_witness_expand, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, (const uint64_t *)d_cw, (const uint32_t *)d_off, (const uint4 *)d_dense, nv, (uint4 *)(dz + 1));
+        VSP_LAUNCH_CHECK();
+    }
     // evaluation vectors (witness_map part 1): A z, B z, C z, plus the rows "input_i * 0 = 0" in A
     VSP_HIP(hipMemsetAsync(dA, 0, m * sizeof(Fr), st));
     VSP_HIP(hipMemsetAsync(dB, 0, m * sizeof(Fr), st));
@@ -216,7 +322,6 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
         VSP_TRY(msm_slot_use_stream(ctx, 1, ctx->prove_streams[0])); VSP_TRY(msm_slot_use_stream(ctx, 2, ctx->prove_streams[0]));
         VSP_TRY(msm_slot_use_stream(ctx, 3, ctx->prove_streams[1])); VSP_TRY(msm_slot_use_stream(ctx, 4, ctx->prove_streams[1]));
     }
-    XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
     VSP_TRY(msm_slot_census(ctx, 1, dz, nv + 1));
     VSP_TRY(msm_slot_census(ctx, 4, dz + ni + 1, nv - ni));
     VSP_HIP(hipEventRecord(ctx->ev_aux, st));          // z resident and censuses queued
@@ -252,6 +357,23 @@ static int prove_queued(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, cons
         VSP_TRY(launch_on_bases(ctx, 0, pk->H, 0, m - 1, dH, VSP_MSM_DENSE));
     }
     lap("prove_launch_ms");
+    // what the second half needs: the key, the randomness, the SAVER term
+    ctx->prove.active = true; ctx->prove.pk = pk;
+    memcpy(ctx->prove.r, r, 32); memcpy(ctx->prove.s, s, 32);
+    ctx->prove.has_saver = saver_P1 && saver_r_enc;
+    if (ctx->prove.has_saver) { memcpy(ctx->prove.P1, saver_P1, 96); memcpy(ctx->prove.r_enc, saver_r_enc, 32); }
+    return VSP_OK;
+}
+
+static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192], const std::function<void()> *overlap) {
+    const vsp_pk *pk = ctx->prove.pk;
+    const uint64_t *r = ctx->prove.r, *s = ctx->prove.s;
+    const uint64_t *saver_P1 = ctx->prove.has_saver ? ctx->prove.P1 : nullptr, *saver_r_enc = ctx->prove.has_saver ? ctx->prove.r_enc : nullptr;
+    VSP_HIP(hipSetDevice(ctx->device));
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *name) { double t = now(); ctx->stats[name] += t - t_prev; t_prev = t; };
+    XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
     // host work that needs no MSM result, done while the GPU runs
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
