@@ -51,7 +51,7 @@ def test_msm_vs_c_oracle_random(ctx, cref, n, group):
     assert np.array_equal(v.multiexp(ctx, bases, ss, group), exp)
 
 
-@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16])
+@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16, 17, 19, 22, 23])
 def test_msm_every_window_size(ctx, cref, window_bits):
     n = 700
     bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=1))
@@ -64,6 +64,50 @@ def test_msm_every_window_size(ctx, cref, window_bits):
         assert ctx.stat("msm_window_bits") == window_bits
     finally:
         ctx.set_option("msm_window_bits", 0)
+
+
+@pytest.mark.parametrize("window_bits", [17, 18, 19, 20, 21, 22, 23])
+def test_msm_windows_wider_than_16_bits_through_the_two_pass_sort(ctx, cref, window_bits):
+    """c = 17 .. 23: the LDS counting sort over the high 15 bits of the bucket index, k_segment_sort over the low
+    c - 16, two-digit bucket reduction with digits of up to 2^11 values through k_dimbits -- G1 (plain, with and without the endomorphism
+    split, and over a table of window multiples sharing one bucket set) and G2, against the C oracle; skewed scalars (zeros, ones, one
+    value repeated: a segment of thousands of entries for one wave) included"""
+    n = 40000 if window_bits < 22 else 34000
+    ks, ss = rand_fr_array(n, seed=100 + window_bits), rand_fr_array(n, seed=200 + window_bits)
+    ss[0] = L(o.R - 1, 4); ss[1] = L(1, 4); ss[2] = 0
+    ss[100:4000] = ss[99]                                           # one value 3900 times: every window has one crowded bucket
+    ss[5000:9000] = 0; ss[5000:9000:2, 0] = 1                       # zeros and ones
+    b1 = cref.g1_batch_mul_gen(ks)
+    want = cref.msm_g1(b1, ss)
+    ctx.set_option("msm_window_bits", window_bits)
+    try:
+        for glv in (1, 0):
+            ctx.set_option("msm_glv", 2 * glv)
+            B = ctx.upload_bases(b1, 1); d_s = ctx.to_device(ss)
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, want), (window_bits, glv)
+            assert ctx.stat("msm_window_bits") == window_bits and ctx.stat("msm_endomorphism_split") == glv
+            if not glv and window_bits in (17, 20):
+                part, _ = B.msm(d_s + 777 * 32, 35000 - 777, 777)   # a sub-range of the resident bases
+                assert np.array_equal(part, cref.msm_g1(b1[777:35000], ss[777:35000]))
+            B.free(); ctx.dfree(d_s)
+        if window_bits in (17, 20, 22):                             # window multiples: all windows share ONE set of 2^(c-1) buckets
+            ctx.set_option("msm_window_bits", 0)
+            m1 = 33000
+            B = ctx.upload_bases(b1[:m1], 1).precompute(window_bits); d_s = ctx.to_device(ss[:m1])
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, cref.msm_g1(b1[:m1], ss[:m1])) and ctx.stat("msm_window_bits") == window_bits and ctx.stat("msm_bucket_sets") == 1
+            B.free(); ctx.dfree(d_s)
+            ctx.set_option("msm_window_bits", window_bits)
+        if window_bits in (17, 19, 21):
+            m2 = 33000
+            b2 = cref.g2_batch_mul_gen(ks[:m2])
+            B = ctx.upload_bases(b2, 2); d_s = ctx.to_device(ss[:m2])
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, cref.msm_g2(b2, ss[:m2]))
+            B.free(); ctx.dfree(d_s)
+    finally:
+        ctx.set_option("msm_window_bits", 0); ctx.set_option("msm_glv", 1)
 
 
 @pytest.mark.parametrize("kind", ["all_zero", "all_one", "boolean_90", "all_equal", "small"])

@@ -420,7 +420,7 @@ int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) {
         unsigned lg = ceil_log2(b->n ? b->n : 1);
         window_bits = lg < 11 ? 8 : (lg - 3 > 16 ? 16 : lg - 3);
     }
-    if (window_bits < 8 || window_bits > 16) return set_error(ctx, VSP_ERR_ARG, "precompute: window_bits must be 8..16");
+    if (window_bits < 8 || window_bits > 22) return set_error(ctx, VSP_ERR_ARG, "precompute: window_bits must be 8..22");
     if (b->pre_c == window_bits) return VSP_OK;
     if (b->pre_c) return set_error(ctx, VSP_ERR_ARG, "precompute: bases already precomputed for another window size");
     if (b->n == 0) { b->pre_c = window_bits; return VSP_OK; }

@@ -47,13 +47,15 @@ struct MsmGeom {
     unsigned single;    // 1 in the shared-set mode
     uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
     unsigned sbits;     // bits of a scalar the windows must cover: 255, or 128 for the two halves of an endomorphism-split scalar
+    unsigned lb;        // windows wider than 16 bits: the low bits of the bucket index that the second sort pass orders (c - 16); 0 otherwise
+    unsigned bd;        // slots per digit in the k_dimbits result layout: 8 (digits of up to 8 bits, three of them) or 12 (two digits of up to 12 bits)
 };
 // reference to the precomputed window multiples of resident bases
 struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
-    static constexpr size_t PINNED_BYTES = 128 * 1024;
+    static constexpr size_t PINNED_BYTES = 256 * 1024;
     bool inited = false, own_stream = false, active = false, empty = false;
     bool dimbits = false;                  // layout of the window results of the last launch (msm_impl.inc k_dimbits / k_dimweight)
     hipStream_t stream = nullptr;          // the stream launches queue on: the slot's own one, or a borrowed one (msm_slot_use_stream)
@@ -62,6 +64,7 @@ struct MsmWork {
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres, medium, redo;
     DevBuf buckets28, partials28;          // G1: bucket sums in the 14 x 28-bit form (fp28.h XYZZ<Fp28>)
+    DevBuf tmp_sorted, tmp_lo, off_hi, cnt_hi;      // windows wider than 16 bits: the entries ordered by the high 15 bits of the bucket index, their low bits, the segment offsets
     DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
     bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
     void *h_pinned = nullptr;
