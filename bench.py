@@ -751,7 +751,7 @@ def main():
         prob = ShardProblem(ctx, v, torch, dev, group, total, world, rank, seed=77 + group,
                             sample=0 if args.no_cpu_baseline else (1 << 20 if group == 1 else 1 << 17))
         ctx.stats_reset()
-        elapsed, result = run_sharded(prob, args.steps, args.warmup, exchange, barrier, depth)
+        elapsed, result = run_sharded(prob, args.steps, max(args.warmup, depth), exchange, barrier, depth)      # one warm-up per work slot: their multi-GB workspaces are allocated on first use
         elapsed = allmax(elapsed)
         pipe_ms = accum_stats()
         main_c, main_w, main_split = int(ctx.stat("msm_window_bits")), int(ctx.stat("msm_windows")), int(ctx.stat("msm_endomorphism_split"))

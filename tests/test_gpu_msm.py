@@ -66,20 +66,25 @@ def test_msm_every_window_size(ctx, cref, window_bits):
         ctx.set_option("msm_window_bits", 0)
 
 
+@pytest.mark.parametrize("sort_mode", [1, 2])
 @pytest.mark.parametrize("window_bits", [17, 18, 19, 20, 21, 22, 23])
-def test_msm_windows_wider_than_16_bits_through_the_two_pass_sort(ctx, cref, window_bits):
+def test_msm_windows_wider_than_16_bits_through_the_two_pass_sort(ctx, cref, window_bits, sort_mode):
     """c = 17 .. 23: the LDS counting sort over the high 15 bits of the bucket index, k_segment_sort over the low
     c - 16, two-digit bucket reduction with digits of up to 2^11 values through k_dimbits -- G1 (plain, with and without the endomorphism
     split, and over a table of window multiples sharing one bucket set) and G2, against the C oracle; skewed scalars (zeros, ones, one
-    value repeated: a segment of thousands of entries for one wave) included"""
+    value repeated: a segment of thousands of entries for one wave, and of more than 8192 for the staged sort's third pass) included"""
     n = 40000 if window_bits < 22 else 34000
     ks, ss = rand_fr_array(n, seed=100 + window_bits), rand_fr_array(n, seed=200 + window_bits)
     ss[0] = L(o.R - 1, 4); ss[1] = L(1, 4); ss[2] = 0
     ss[100:4000] = ss[99]                                           # one value 3900 times: every window has one crowded bucket
     ss[5000:9000] = 0; ss[5000:9000:2, 0] = 1                       # zeros and ones
+    ss[10000:19400] = ss[9999]                                      # 9400 times: longer than one wave orders (MS_SEG_LONG): the third pass, in every window
+    ss[20000:29000] = 0; ss[20000:29000, 0] = 1 + (np.arange(9000) % 3 == 0)      # ones and twos: one long segment, two buckets in it (c >= 18)
     b1 = cref.g1_batch_mul_gen(ks)
     want = cref.msm_g1(b1, ss)
-    ctx.set_option("msm_window_bits", window_bits)
+    # sort_mode 1: LDS counting sort over the high 15 bits + k_segment_sort; 2: the staged sort of large problems (8 + 8 bits through LDS
+    # tiles, the rest inside LDS: k_ms_*), forced here at a size the oracle can follow
+    ctx.set_option("msm_window_bits", window_bits); ctx.set_option("msm_sort", sort_mode)
     try:
         for glv in (1, 0):
             ctx.set_option("msm_glv", 2 * glv)
@@ -107,7 +112,7 @@ def test_msm_windows_wider_than_16_bits_through_the_two_pass_sort(ctx, cref, win
             assert np.array_equal(got, cref.msm_g2(b2, ss[:m2]))
             B.free(); ctx.dfree(d_s)
     finally:
-        ctx.set_option("msm_window_bits", 0); ctx.set_option("msm_glv", 1)
+        ctx.set_option("msm_window_bits", 0); ctx.set_option("msm_glv", 1); ctx.set_option("msm_sort", 0)
 
 
 @pytest.mark.parametrize("kind", ["all_zero", "all_one", "boolean_90", "all_equal", "small"])

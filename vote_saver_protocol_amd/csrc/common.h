@@ -64,6 +64,7 @@ struct MsmWork {
     DevBuf cnt, off, cursor, nsub, suboff, blocksum, sorted, heavy, counters, digits, blockhist, partbucket, perm, sizehist;
     DevBuf buckets, partials, dims, winres, medium, redo;
     DevBuf buckets28, partials28;          // G1: bucket sums in the 14 x 28-bit form (fp28.h XYZZ<Fp28>)
+    DevBuf pairs_a, pairs_b, ms_h1, ms_h1s, ms_h2, ms_h2s;      // staged sort of large wide-window problems (msm_impl.inc k_ms_*)
     DevBuf tmp_sorted, tmp_lo, off_hi, cnt_hi;      // windows wider than 16 bits: the entries ordered by the high 15 bits of the bucket index, their low bits, the segment offsets
     DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
     bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
