@@ -51,7 +51,7 @@ def test_msm_vs_c_oracle_random(ctx, cref, n, group):
     assert np.array_equal(v.multiexp(ctx, bases, ss, group), exp)
 
 
-@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16, 17, 19, 22, 23])
+@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16, 17, 18, 19, 20, 21, 22, 23])
 def test_msm_every_window_size(ctx, cref, window_bits):
     n = 700
     bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=1))

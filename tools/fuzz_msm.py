@@ -49,7 +49,8 @@ while time.time() - t0 < budget:
     elif kind == "edges":
         for k in range(0, n, 7): ss[k] = L(o.R - 1 - int(rng.integers(0, 3)), 4)
         for k in range(3, n, 11): ss[k] = 0
-    wb = int(rng.choice([0, 0, 0, 5, 8, 11, 13, 16]))
+    wb = int(rng.choice([0, 0, 0, 5, 8, 11, 13, 16, 17, 18, 19, 20, 21, 22]))
+    sort_mode = int(rng.choice([0, 1, 2])); ctx.set_option("msm_sort", sort_mode)      # policy / never staged / staged from c = 12 on
     pre = bool(rng.random() < 0.5)
     ctx.set_option("msm_window_bits", wb)
     ctx.set_option("msm_split", int(rng.choice([0, 0, 0, 16, 64])))
@@ -58,7 +59,7 @@ while time.time() - t0 < budget:
     B = ctx.upload_bases(bases, group)
     try:
         if pre:
-            B.precompute(wb if 8 <= wb <= 16 else 0)
+            B.precompute(wb if 8 <= wb <= 22 else 0)
         d_s = ctx.to_device(ss)
         first = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
         cnt = n - first
@@ -71,5 +72,5 @@ while time.time() - t0 < budget:
         B.free()
     key = (group, pre, kind, glv); stats[key] = stats.get(key, 0) + 1
     if not ok:
-        print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, kind=kind, wb=wb, pre=pre, glv=glv, first=first, dup=dup < 0.15)); sys.exit(1)
+        print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, kind=kind, wb=wb, sort_mode=sort_mode, pre=pre, glv=glv, first=first, dup=dup < 0.15)); sys.exit(1)
 print("fuzz ok: %d configurations in %.0f s" % (it, time.time() - t0), {str(k): c for k, c in sorted(stats.items())})
