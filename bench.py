@@ -540,7 +540,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary NTT / G2 / resident-key measurements")
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--pipeline-depth", type=int, default=3, help="MSMs in flight (work slots with their own streams)")
+    ap.add_argument("--pipeline-depth", type=int, default=4, help="MSMs in flight (work slots with their own streams)")
+    ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process unless already in the environment; 0 = leave the runtime's default (4)")
     ap.add_argument("--no-pipeline", action="store_true", help="blocking MSM calls (one in flight): for clean per-kernel profiles")
     ap.add_argument("--precompute", action="store_true", help="headline over a resident key with window multiples (16x table) instead of plain bases")
     ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
@@ -563,12 +564,17 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    # The HIP runtime maps every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4) per priority.  This process
-    # ends up with a dozen streams (torch's, the context's, six work slots', the prover's two chains); with four queues the prover's two
-    # witness chains shared one and a proof took 7.4 ms instead of 6.6 ms.  Eight queues, unless the caller set a value;
-    # it has to be in the environment before the runtime initialises, i.e. before torch is imported.
-    if os.environ.get("VSP_BENCH_HW_QUEUES"):                 # experiment knob only: the library no longer depends on the runtime's queue count
+    # The HIP runtime maps every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4) per priority.  Results never
+    # depend on it, and a single proof's latency does not either (the prover's two chains get their queues first, capi.hip vsp_create);
+    # multi-exponentiations IN FLIGHT TOGETHER overlap better with eight: 2.86-2.91 ms per 2^20-point step against 3.03-3.11 with four
+    # (round 3, depth 3 / 4, same box; slot streams spread over the priority pools did not change the four-queue figure, so it is not two
+    # slots sharing a queue).  A deployment knob like NCCL_*: set here unless the caller set a value or passed --hw-queues 0, reported in
+    # the JSON line (config.runtime_env), documented in include/vsp.h.  It has to be in the environment before the runtime initialises,
+    # i.e. before torch is imported.
+    if os.environ.get("VSP_BENCH_HW_QUEUES"):                 # older spelling of --hw-queues
         os.environ["GPU_MAX_HW_QUEUES"] = os.environ["VSP_BENCH_HW_QUEUES"]
+    elif args.hw_queues > 0:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))
     import torch
     import torch.distributed as dist
     import vote_saver_protocol_amd as v
@@ -773,7 +779,8 @@ def main():
                "config": {"workload": f"one 2^{lg_total}-point BLS12-381 {args.group.upper()} Pippenger MSM, plain bases k_i*G (64-bit k_i), uniform 254-bit scalars, "
                                       f"resident in HBM; rank g holds the contiguous chunk g of {world}; one all-gather ({exchange.backend}) of {144 * group}-byte Jacobian records + local fold per MSM",
                           "total_points": total, "points_per_gpu": prob.n, "window_bits": main_c, "windows": main_w, "msms_in_flight": depth,
-                          "exchange_backend": exchange.backend, "ranks_seen_by_collective": ranks_seen, "gpus_visible": n_dev},
+                          "exchange_backend": exchange.backend, "ranks_seen_by_collective": ranks_seen, "gpus_visible": n_dev,
+                          "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}},
                "verified_bit_exact": verified, "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3, "roofline": rl, "roofline_valu": rv,
                "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all}
         if rank == 0:
@@ -975,7 +982,8 @@ def main():
                    "points_per_gpu": n, "window_bits": main_c, "windows": main_w, "endomorphism_split": bool(main_split), "msms_in_flight": depth,
                    "bases_precomputed_window_multiples": bool(args.precompute),
                    "bases_memory_bytes_per_point": (16 * (96 + 128)) if args.precompute else (96 + 2 * 128),
-                   "precompute_once_s": precompute_s},
+                   "precompute_once_s": precompute_s,
+                   "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}},
         "verified_bit_exact": verified,
         "latency_ms_one_in_flight": ex_elapsed / ex_steps * 1e3,
         "roofline": rl,

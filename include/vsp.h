@@ -87,7 +87,15 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * (first 28-bit table of a group) and "ntt_fr29_selfcheck" (first transform): 1 passed, -1 failed (the context then runs the generic
  * kernels for its lifetime and vsp_last_error says so), 0 could not run;
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
- * multi-exponentiation -- a blocking read-back). */
+ * multi-exponentiation -- a blocking read-back); "msm_sort" (0: by size; 1: never the staged sort of large wide-window problems;
+ * 2: the staged sort for every window of 12 bits and more), "msm_wide_windows" (0: never more than 16 bits per window).
+ *
+ * Runtime environment.  Results never depend on it.  GPU_MAX_HW_QUEUES (HIP runtime, read once when the runtime starts; default 4
+ * hardware queues per stream priority): one proof's latency does not depend on it (the prover's two chains take their queues when the
+ * context is created), but independent multi-exponentiations kept IN FLIGHT TOGETHER over the work slots overlap better with 8
+ * (2^20 G1 points, four in flight: 2.86 ms per multi-exponentiation against 3.03 with the default 4; MI355X, ROCm 7.2).  A service that
+ * pipelines proofs or multi-exponentiations should export GPU_MAX_HW_QUEUES=8 before the process's first HIP call;
+ * vsp_get_stat("runtime_hw_queues_env") is the value this process saw (0: not set). */
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
 /* Diagnostic build only (libvsp_hip_diag.so, `make -C vote_saver_protocol_amd/csrc diag`: the same sources with stamps around the G1
  * accumulation loop -- in the shipped library no stamp executes and this returns VSP_ERR_UNSUPPORTED): the clock the chip held inside

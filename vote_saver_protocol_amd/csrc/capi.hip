@@ -166,6 +166,7 @@ int vsp_synchronize(vsp_ctx *ctx) {
 }
 double vsp_get_stat(vsp_ctx *ctx, const char *name) {
     if (!ctx || !name) return 0.0;
+    if (!strcmp(name, "runtime_hw_queues_env")) { const char *q = getenv("GPU_MAX_HW_QUEUES"); return q ? atof(q) : 0.0; }      // include/vsp.h "Runtime environment"
     auto it = ctx->stats.find(name);
     return it == ctx->stats.end() ? 0.0 : it->second;
 }
