@@ -51,19 +51,25 @@ def test_msm_vs_c_oracle_random(ctx, cref, n, group):
     assert np.array_equal(v.multiexp(ctx, bases, ss, group), exp)
 
 
-@pytest.mark.parametrize("window_bits", [4, 7, 10, 13, 16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("window_bits", [3, 4, 5, 7, 10, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23])
 def test_msm_every_window_size(ctx, cref, window_bits):
     n = 700
     bases = cref.g1_batch_mul_gen(rand_fr_array(n, seed=1))
     ss = rand_fr_array(n, seed=2)
     ss[0] = L(o.R - 1, 4); ss[1] = L(1, 4); ss[2] = 0
+    ss[3] = L((o.R - 1) // 2, 4); ss[4] = L((o.R + 1) // 2, 4); ss[5] = L(o.R - 2, 4)      # either side of the fold k -> min(k, r - k) (c = 3, 5, 15, 17)
+    ss[6] = L((1 << 254) - 1, 4); ss[7] = L(1 << 254, 4); ss[8] = L(o.R - (1 << 254), 4)
     exp = cref.msm_g1(bases, ss)
     ctx.set_option("msm_window_bits", window_bits)
     try:
         assert np.array_equal(v.multiexp(ctx, bases, ss, 1), exp)
         assert ctx.stat("msm_window_bits") == window_bits
+        assert ctx.stat("msm_windows") == (254 if 255 % window_bits == 0 else 255) // window_bits + 1
+        if 255 % window_bits == 0:                                 # the same without the fold: one window more, same point
+            ctx.set_option("msm_fold", 0)
+            assert np.array_equal(v.multiexp(ctx, bases, ss, 1), exp)
     finally:
-        ctx.set_option("msm_window_bits", 0)
+        ctx.set_option("msm_window_bits", 0); ctx.set_option("msm_fold", 1)
 
 
 @pytest.mark.parametrize("sort_mode", [1, 2])

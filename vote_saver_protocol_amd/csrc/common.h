@@ -48,6 +48,7 @@ struct MsmGeom {
     uint32_t idx_stride, idx_first;   // shared-set mode: sorted entry of digit w of scalar i = w * idx_stride + idx_first + i
     unsigned sbits;     // bits of a scalar the windows must cover: 255, or 128 for the two halves of an endomorphism-split scalar
     unsigned lb;        // windows wider than 16 bits: the low bits of the bucket index that the second sort pass orders (c - 16); 0 otherwise
+    unsigned fold;      // 255-bit scalars are read as min(k, r - k) < 2^254 with the sign flipped: one window fewer where c divides 255 (c = 15, 17)
     unsigned bd;        // slots per digit in the k_dimbits result layout: 8 (digits of up to 8 bits, three of them) or 12 (two digits of up to 12 bits)
 };
 // reference to the precomputed window multiples of resident bases
