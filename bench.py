@@ -890,6 +890,13 @@ def main():
                                            "valu_frac_of_mad_issue_peak": (mads / 64.0 / N_SIMD * issue_costs()[0]["mad"]) / (dtn * (clock_info["ghz"] if clock_info else 2.1) * 1e9),
                                            "valu_frac_note": "multiply-adds alone at the SIMD's issue cost (profiles/r3_ubench_issue.txt) over the transform's cycles at the clock "
                                                              "the accumulation loop held in this run (the transform's own in-kernel clock is not stamped)",
+                                           # the whole instruction stream (disassembly of k_ntt29_pass): a radix-4 butterfly = 4 products of 162 mads + 46
+                                           # simple instructions, + ~400 simple ones around them; per element of the last pass one more product + ~150; ~100 per element and pass
+                                           "valu_frac_of_instruction_mix_peak": ((((1 << lg) / 4.0) * (lg / 2.0) * (4 * (162 * issue_costs()[0]["mad"] + 46 * issue_costs()[0]["simple"]) + 400 * issue_costs()[0]["simple"])
+                                                                                  + (1 << lg) * (162 * issue_costs()[0]["mad"] + (46 + 150 + 100 * npass) * issue_costs()[0]["simple"])) / 64.0 / N_SIMD)
+                                                                                / (dtn * (clock_info["ghz"] if clock_info else 2.1) * 1e9) if f29 else None,
+                                           "knock_out_timings_ms": {"as_built": 0.60, "products_replaced_by_additions": 0.37, "no_twiddle_loads": 0.52, "no_step_barriers": 0.59,
+                                                                    "note": "2^22 forward, round 3 (variant builds, not shipped): the time is memory side + products, not their maximum -- DESIGN.md 3.2"},
                                            "note": "integer-VALU bound: 11 Fr products per element (22 stages as radix-4 steps); the mads alone are a third of the "
                                                    "instructions of a butterfly; see DESIGN.md 3.2"}
             del a
