@@ -506,6 +506,35 @@ def test_msm_g1_2p23_config5_shard_plain_bases(ctx, cref):
         B.free(); ctx.dfree(d_b); ctx.dfree(d_s)
 
 
+@pytest.mark.parametrize("window_bits", [0, 20, 22])
+def test_msm_staged_sort_at_scale_with_crowded_buckets(ctx, cref, window_bits):
+    """2^22 points through the staged sort (k_ms_*) with scalars that crowd it: half of them ONE value (a bucket of 2^21 entries in every
+    window: hundreds of pieces in the second and third splitting passes, thousands of parts in the heavy-bucket merge), a quarter below
+    2^6 (the low window's first segment holds 2^20 entries in a few buckets), zeros, ones, the rest uniform.  The discrete-log identity
+    on the whole problem; the policy's window (17 bits, scalars folded: 15 windows) and two wider ones."""
+    n = 1 << 22
+    ks = rand_fr_array(n, seed=301); ss = rand_fr_array(n, seed=302)
+    ss[: n // 2] = ss[n // 2]
+    ss[n // 2: 3 * n // 4] = 0; ss[n // 2: 3 * n // 4, 0] = np.arange(n // 4, dtype=np.uint64) % 64
+    ss[3 * n // 4: 3 * n // 4 + 65536] = 0; ss[3 * n // 4 + 32768: 3 * n // 4 + 65536, 0] = 1
+    d_k = ctx.to_device(ks); d_s = ctx.to_device(ss)
+    d_b = v.fixed_base_mul(ctx, d_k, n, 1)
+    ctx.dfree(d_k)
+    ctx.set_option("msm_census_sync", 1)                          # plan from this vector's own 0 / 1 census
+    B = ctx.bases_from_device(d_b, n, 1)
+    ctx.set_option("msm_window_bits", window_bits)
+    try:
+        got, inf = B.msm(d_s)
+        e = _dlog_identity(ks, ss)
+        assert not inf and np.array_equal(got, cref.g1_mul(g1_limbs(o.G1.gen), L(e, 4)))
+        assert ctx.stat("msm_window_bits") == (window_bits or 17)
+        if not window_bits:
+            assert ctx.stat("msm_windows") == 15
+    finally:
+        ctx.set_option("msm_window_bits", 0); ctx.set_option("msm_census_sync", 0)
+        B.free(); ctx.dfree(d_b); ctx.dfree(d_s)
+
+
 def test_msm_g2_2p21_config5_shard_plain_bases(ctx, cref):
     """BASELINE config 5, the per-GPU share of the G2 half: 2^24 points over 8 GPUs = 2^21 per rank, plain bases; the identity on
     the whole shard, a 2^12-point slice against the C oracle, and the 288-byte Jacobian record."""
