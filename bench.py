@@ -516,6 +516,11 @@ def run_sharded(problem, steps, warmup, exchange, barrier, depth):
     of step k completes while step k + 1's multi-exponentiation is awaited); returns (seconds for `steps`, last folded result)"""
     from vote_saver_protocol_amd.sharded import ShardedMsm
     job = ShardedMsm(problem.bases, exchange)
+    if depth > 1:
+        # set-up, not a step: the first multi-exponentiation on a work slot allocates that slot's workspaces, pinned buffers and stream
+        # (15-20 ms), and W warm-up steps touch only min(W, depth - 1) + ... of the `depth` slots (W = 3, depth = 4: the fourth slot's first
+        # use fell inside the timed region -- 5.06 instead of 3.16 ms per step over 10 steps through the nccl path)
+        job.run(problem.d_s, depth, depth)
     if warmup:
         job.run(problem.d_s, warmup, depth)
     barrier(); t0 = time.perf_counter()

@@ -66,11 +66,22 @@ def test_run_sharded_keeps_depth_in_flight_and_folds_every_step():
                     ended.append(h); assert len(begun) >= min(h + 1, steps)      # step h's exchange ends after step h + 1 has begun (or at the very end)
                     return ("folded", h)
 
-            el, res = bench.run_sharded(prob, steps, 0, Exchange(), lambda: None, depth)
-            assert begun == list(range(1, steps + 1)) and ended == begun and res == ("folded", steps) and el >= 0
+            from vote_saver_protocol_amd.sharded import ShardedMsm
+            res = ShardedMsm(prob.bases, Exchange()).run(prob.d_s, steps, depth)
+            assert begun == list(range(1, steps + 1)) and ended == begun and res == ("folded", steps)
             assert prob.bases.in_flight == 0
             slots = {x[1] for x in log if x[0] == "launch"}
             assert len(slots) <= depth and (slots == {0} if depth == 1 else 0 not in slots)      # one in flight: the context's stream; else the slots' own
+
+            # bench.run_sharded around it: every work slot is used once before the warm-up (set-up: first use allocates), then W + K steps
+            class Quiet:
+                def begin(self, bases, slot, buf): return bases.msm_finish_jacobian(slot)
+                def end(self, h): return h
+            prob.bases = Bases(); log.clear()
+            el, _ = bench.run_sharded(prob, steps, 2, Quiet(), lambda: None, depth)
+            assert el >= 0 and prob.bases.count == (depth if depth > 1 else 0) + 2 + steps
+            if depth > 1:
+                assert {x[1] for x in log[:2 * depth] if x[0] == "launch"} == set(ShardedMsm.SLOTS[:depth])
 
 
 def test_launcher_refuses_cleanly_without_gpus_and_never_imports_torch_first():
