@@ -549,6 +549,7 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process unless already in the environment; 0 = leave the runtime's default (4)")
     ap.add_argument("--no-pipeline", action="store_true", help="blocking MSM calls (one in flight): for clean per-kernel profiles")
     ap.add_argument("--precompute", action="store_true", help="headline over a resident key with window multiples (16x table) instead of plain bases")
+    ap.add_argument("--precompute-split", action="store_true", help="with --precompute: the table carries the endomorphism rows (vsp_bases_precompute_split)")
     ap.add_argument("--prove-h-first", type=int, default=-1, help="prover queue order (library option prove_h_first); -1 = library default")
     ap.add_argument("--no-prove", action="store_true", help="skip the secondary full-prover measurement (config 4)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="log2 of the synthetic R1CS domain for the prover measurement")
@@ -812,7 +813,7 @@ def main():
     head.bases = ctx.bases_from_device(d_bases_canon, n, 1)
     precompute_s = None
     if args.precompute:
-        t_pre = time.perf_counter(); head.bases.precompute(16); precompute_s = time.perf_counter() - t_pre
+        t_pre = time.perf_counter(); head.bases.precompute(int(os.environ.get("VSP_BENCH_PRE_C", "16")), split=args.precompute_split); precompute_s = time.perf_counter() - t_pre
 
     ctx.stats_reset()
     elapsed, result = run_sharded(head, args.steps, args.warmup, exchange, barrier, depth)
@@ -860,6 +861,16 @@ def main():
             el2, res2 = run_sharded(pre, k2, 2, exchange, barrier, depth)
             extras["resident_key_window_multiples"] = {"ms_per_step": el2 / k2 * 1e3, "points_per_s": n * k2 / el2, "table_memory_factor": 16, "build_once_s": pre_s,
                                                        "k_accum28_avg_ms_pipelined": accum_stats(), "same_result": bool(np.array_equal(res2, result))}
+            pre.bases.free()
+            # the same key for DENSE scalars: window multiples WITH their endomorphism images (vsp_bases_precompute_split), 19-bit windows:
+            # 7 windows of a split scalar over one bucket set -- 12.5 % fewer additions than the headline's 8, 14 rows of 128 bytes per point
+            pre.bases = ctx.bases_from_device(d_bases_canon, n, 1)
+            t_pre = time.perf_counter(); pre.bases.precompute(19, split=True); pre_s = time.perf_counter() - t_pre
+            ctx.stats_reset()
+            el3, res3 = run_sharded(pre, k2, 2, exchange, barrier, depth)
+            extras["resident_key_window_multiples_split_19bit"] = {"ms_per_step": el3 / k2 * 1e3, "points_per_s": n * k2 / el3, "rows_per_point": 14, "build_once_s": pre_s,
+                                                                   "windows": int(ctx.stat("msm_windows")), "k_accum28_avg_ms_pipelined": accum_stats(),
+                                                                   "same_result": bool(np.array_equal(res3, result))}
             pre.bases.free()
 
         if world == 1 and not args.no_extras:

@@ -133,6 +133,11 @@ vsp_bases *vsp_bases_from_device_g2(vsp_ctx *ctx, const void *d_bases, size_t n)
  * 2^(c-1) buckets for all windows: the bucket reduction shrinks by the number of windows and the work per thread is uniform.
  * Results are identical; sub-range calls (first, n) keep working. */
 int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits);
+/* The same table for bases whose scalars are DENSE (the H query; not witness vectors, whose scalars are mostly 0 / 1): beside every window
+ * multiple its image under the curve's endomorphism, for the ceil(128 / c) windows of a split scalar k = k1 + k2 lambda -- the
+ * endomorphism split of "msm_glv" over ONE bucket set.  Same memory as the plain table at c = 16 (8 windows x 2 rows instead of 16).
+ * Needs the order-r subgroup: bases not yet checked are checked here ("bases_check_subgroup"); bases outside it get the plain table. */
+int vsp_bases_precompute_split(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits);
 size_t vsp_bases_count(const vsp_bases *b);
 /* device memory the handle holds: the Montgomery-form points (or the table of window multiples) plus the 28-bit-limb copy */
 size_t vsp_bases_device_bytes(const vsp_bases *b);

@@ -506,6 +506,39 @@ def test_msm_g1_2p23_config5_shard_plain_bases(ctx, cref):
         B.free(); ctx.dfree(d_b); ctx.dfree(d_s)
 
 
+@pytest.mark.parametrize("group,n", [(1, 6000), (2, 3000)])
+def test_msm_window_multiples_with_the_endomorphism_rows(ctx, cref, group, n):
+    """vsp_bases_precompute_split: the table of window multiples for DENSE scalars -- (2^(cw) P, phi(2^(cw) P)) for the ceil(128 / c) windows
+    of a split scalar, all windows sharing one bucket set.  Against the C oracle for several window sizes, with a sub-range of the
+    resident bases, crowded buckets, zeros and ones; bases outside the subgroup keep the ordinary table and the exact sum."""
+    ks, ss = rand_fr_array(n, seed=7), rand_fr_array(n, seed=8)
+    ss[0] = L(o.R - 1, 4); ss[1] = L(1, 4); ss[2] = 0; ss[100:400] = ss[99]; ss[500:900] = 0; ss[500:900:2, 0] = 1
+    b = cref.g1_batch_mul_gen(ks) if group == 1 else cref.g2_batch_mul_gen(ks)
+    fn = cref.msm_g1 if group == 1 else cref.msm_g2
+    want = fn(b, ss)
+    for wb in (8, 13, 16, 19, 0):
+        B = ctx.upload_bases(b, group).precompute(wb, split=True); d_s = ctx.to_device(ss)
+        try:
+            got, _ = B.msm(d_s)
+            assert np.array_equal(got, want), wb
+            assert ctx.stat("msm_endomorphism_split") == 1 and ctx.stat("msm_bucket_sets") == 1
+            if wb:
+                assert ctx.stat("msm_windows") == (128 + wb - 1) // wb
+            part, _ = B.msm(d_s + 32 * 123, n - 500 - 123, 123)
+            assert np.array_equal(part, fn(b[123:n - 500], ss[123:n - 500])), wb
+        finally:
+            B.free(); ctx.dfree(d_s)
+    if group == 1:                                                 # a point with a cofactor component: no endomorphism rows, same exact sum
+        from test_gpu_subgroup import curve_point_outside_g1
+        b2 = b.copy(); b2[5] = g1_limbs(curve_point_outside_g1(7))
+        B = ctx.upload_bases(b2, 1).precompute(13, split=True); d_s = ctx.to_device(ss)
+        try:
+            got, _ = B.msm(d_s)
+            assert ctx.stat("msm_endomorphism_split") == 0 and np.array_equal(got, cref.msm_g1(b2, ss))
+        finally:
+            B.free(); ctx.dfree(d_s)
+
+
 @pytest.mark.parametrize("window_bits", [0, 20, 22])
 def test_msm_staged_sort_at_scale_with_crowded_buckets(ctx, cref, window_bits):
     """2^22 points through the staged sort (k_ms_*) with scalars that crowd it: half of them ONE value (a bucket of 2^21 entries in every

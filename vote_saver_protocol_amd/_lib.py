@@ -39,6 +39,7 @@ PROTOTYPES = {
     "vsp_bases_from_device_g1": (_P, [_P, _P, _SZ]),
     "vsp_bases_from_device_g2": (_P, [_P, _P, _SZ]),
     "vsp_bases_precompute": (_I, [_P, _P, _U]),
+    "vsp_bases_precompute_split": (_I, [_P, _P, _U]),
     "vsp_bases_count": (_SZ, [_P]),
     "vsp_bases_device_bytes": (_SZ, [_P]),
     "vsp_keypair_device_bytes": (_SZ, [_P]),

@@ -149,9 +149,11 @@ class Bases:
             self.ctx.lib.vsp_bases_free(self.ctx.h, self.h)
         self.h = None
 
-    def precompute(self, window_bits=0):
-        """Store the window multiples 2^(c*w) * P once (16x memory at c = 16); later multi-exponentiations share one bucket set."""
-        self.ctx.check(self.ctx.lib.vsp_bases_precompute(self.ctx.h, self.h, window_bits))
+    def precompute(self, window_bits=0, split=False):
+        """Store the window multiples 2^(c*w) * P once (16x memory at c = 16); later multi-exponentiations share one bucket set.
+        split=True (bases whose scalars are dense, e.g. the H query): the table carries the endomorphism rows for split scalars."""
+        fn = self.ctx.lib.vsp_bases_precompute_split if split else self.ctx.lib.vsp_bases_precompute
+        self.ctx.check(fn(self.ctx.h, self.h, window_bits))
         return self
 
     def msm(self, d_scalars, n=None, first=0):

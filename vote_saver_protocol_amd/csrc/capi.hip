@@ -315,7 +315,12 @@ static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
     if (!want || !fp28_known_answer_check(ctx, b->group)) return;                 // the check may have just switched "msm_fp28" off
     const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
-    const bool glv = glv_wanted(ctx, b->group, count, b->pre_c) && (b->in_subgroup > 0 || want_glv >= 2);
+    bool glv = glv_wanted(ctx, b->group, count, b->pre_c) && (b->in_subgroup > 0 || want_glv >= 2);
+    if (b->pre_c && b->pre_split && want_glv && (b->in_subgroup > 0 || want_glv >= 2)) {
+        // window multiples for dense scalars: the 128 / c windows of a split scalar, every row with its endomorphism image beside it
+        glv = true;
+        count = b->n * ((128 + b->pre_c - 1) / b->pre_c);
+    }
     void *t28 = nullptr;
     if (hipMalloc(&t28, count * row * (glv ? 2 : 1)) != hipSuccess) { hipGetLastError(); return; }
     int rc = b->group == 1 ? msm_g1_table28(ctx, (const G1Affine *)b->d, count, t28, glv) : msm_g2_table28(ctx, (const G2Affine *)b->d, count, t28, glv);
@@ -384,7 +389,8 @@ size_t vsp_bases_device_bytes(const vsp_bases *b) {
     if (!b) return 0;
     const size_t slices = b->pre_c ? 255 / b->pre_c + 1 : 1, count = b->n * slices;
     const size_t esz = b->group == 1 ? sizeof(G1Affine) : sizeof(G2Affine), row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
-    return (count ? count * esz : 16) + (b->d28 ? count * row * (b->glv ? 2 : 1) : 0);
+    const size_t rows28 = (b->pre_c && b->glv) ? b->n * ((128 + b->pre_c - 1) / b->pre_c) * 2 : count * (b->glv ? 2 : 1);
+    return (count ? count * esz : 16) + (b->d28 ? rows28 * row : 0);
 }
 void vsp_bases_free(vsp_ctx *ctx, vsp_bases *b) {
     if (!b) return;
@@ -401,9 +407,9 @@ namespace vsp {
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot) {
     if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
     if (bases->pre_c) {
-        MsmPre pre{bases->n, first, bases->pre_c, bases->d28};
-        if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
-        return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d, d_scalars, n, plan_from_slot, &pre);
+        MsmPre pre{bases->n, first, bases->pre_c, bases->d28, bases->glv};
+        if (bases->group == 1) return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d, d_scalars, n, plan_from_slot, &pre, nullptr, bases->glv);
+        return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d, d_scalars, n, plan_from_slot, &pre, nullptr, bases->glv);
     }
     if (bases->group == 1)
         return msm_g1_launch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
@@ -414,9 +420,30 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
 }  // namespace vsp
 extern "C" {
 
-int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) {
+static int bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits, bool split);
+int vsp_bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) { return bases_precompute(ctx, b, window_bits, false); }
+int vsp_bases_precompute_split(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits) { return bases_precompute(ctx, b, window_bits, true); }
+static int bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits, bool split) {
     if (!ctx) return VSP_ERR_ARG;
     if (!b) return set_error(ctx, VSP_ERR_ARG, "precompute: null bases");
+    if (split && b->pre_c == 0) {
+        // the endomorphism rows need the order-r subgroup (include/vsp.h "bases_check_subgroup"): bases that were not checked at upload are checked now
+        long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
+        if (b->in_subgroup == 0 && want_glv == 1 && b->n) {
+            VSP_HIP(hipSetDevice(ctx->device));
+            VSP_TRY(ensure(ctx, ctx->val_flag, 16));
+            VSP_HIP(hipMemsetAsync(ctx->val_flag.p, 0, 4, ctx->stream));
+            VSP_TRY(b->group == 1 ? subgroup_check_g1(ctx, (const G1Affine *)b->d, b->n, (uint32_t *)ctx->val_flag.p)
+                                  : subgroup_check_g2(ctx, (const G2Affine *)b->d, b->n, (uint32_t *)ctx->val_flag.p));
+            uint32_t h_flag = 0;
+            VSP_HIP(hipMemcpyAsync(&h_flag, ctx->val_flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            VSP_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->stats["bases_subgroup_checks"] += 1;
+            b->in_subgroup = (h_flag & 4u) ? -1 : 1;
+            if (h_flag & 4u) ctx->stats["bases_outside_subgroup"] += 1;
+        }
+        b->pre_split = true;                                 // (bases outside the subgroup get the ordinary table: build_table28 decides)
+    }
     if (window_bits == 0) {                     // automatic: about n * W / 2^(c-1) = 256 points per shared bucket
         unsigned lg = ceil_log2(b->n ? b->n : 1);
         window_bits = lg < 11 ? 8 : (lg - 3 > 16 ? 16 : lg - 3);

@@ -52,7 +52,8 @@ struct MsmGeom {
     unsigned bd;        // slots per digit in the k_dimbits result layout: 8 (digits of up to 8 bits, three of them) or 12 (two digits of up to 12 bits)
 };
 // reference to the precomputed window multiples of resident bases
-struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null
+struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; bool glv; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null;
+                                                                                             // glv: table28 holds (2^(cw) P_i, phi(2^(cw) P_i)) interleaved for the 128 / c windows of split scalars
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
@@ -127,8 +128,10 @@ struct vsp_bases {
     unsigned pre_c = 0;
     int in_subgroup = 0;    // 1: every point satisfies phi(P) = lambda P (checked at upload, or the library's own multiples of a generator); -1: the check
                             // found a point that does not; 0: not checked.  The endomorphism layout below needs 1 (or option "msm_glv" = 2)
-    bool glv = false;       // plain bases only: d28 holds 2n rows, (P_i, phi(P_i)) interleaved, phi(x, y) = (beta x, y) = lambda * P (the curve's
-                            // endomorphism): a scalar k = k1 + k2 lambda then needs windows over 128 bits only -- half the bucket sets to reduce
+    bool glv = false;       // d28 holds (P_i, phi(P_i)) interleaved, phi(x, y) = (beta x, y) = lambda * P (the curve's endomorphism): a scalar
+                            // k = k1 + k2 lambda then needs windows over 128 bits only.  Plain bases: 2n rows, half the bucket sets to reduce.
+                            // Window multiples (pre_split): 2n rows for each of the ceil(128 / pre_c) windows -- the split over ONE bucket set
+    bool pre_split = false; // vsp_bases_precompute_split: the table of window multiples is meant for dense scalars and carries the endomorphism rows
     void *d28 = nullptr;    // the same array (or table) once more on 14 x 28-bit limbs (fp28.h: 112-byte rows G1, 224-byte rows G2) for the accumulation kernel
 };
 
