@@ -299,12 +299,15 @@ def header_text(ins):
 
 namespace vsp {{
 
+// The holder only places the routine's text in the code object: entered as a function it branches over the body, so it clobbers
+// nothing.  (The registers the ROUTINE uses are declared where it is entered, accum28_asm below -- in k_accum28's register budget; listed
+// here they made the compiler call v128 .. v166 "reserved" against this function's own default budget of 128.)
 template <int Instance> __device__ __attribute__((noinline, used)) void accum28_holder() {{
     asm volatile(
 {body_txt}
         :
         :
-        : "memory", "vcc", "scc", "s30", "s31", {sclob}, {vclob});
+        : "memory");
 }}
 // acc[56] = X | Y | ZZ | ZZZ of the sum of table[sorted[i] & 0x7fffffff] (negated where bit 31 is set), i in [start, end) -- all zero for an
 // empty range; flag = 1 when an equal-x pair (a doubling or a cancellation) was met: acc is then void and the caller hands the part to
