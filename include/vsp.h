@@ -88,7 +88,9 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * kernels for its lifetime and vsp_last_error says so), 0 could not run;
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
  * multi-exponentiation -- a blocking read-back); "msm_sort" (0: by size; 1: never the staged sort of large wide-window problems;
- * 2: the staged sort for every window of 12 bits and more), "msm_wide_windows" (0: never more than 16 bits per window).
+ * 2: the staged sort for every window of 12 bits and more), "msm_wide_windows" (0: never more than 16 bits per window), "msm_fold" (0: 255-bit
+ * scalars are not folded to min(k, r - k) where the window width divides 255), "msm_fused_split" (0: the endomorphism split and the digit
+ * extraction run as two kernels over the scalars instead of one).
  *
  * Runtime environment.  Results never depend on it.  GPU_MAX_HW_QUEUES (HIP runtime, read once when the runtime starts; default 4
  * hardware queues per stream priority): one proof's latency does not depend on it (the prover's two chains take their queues when the
