@@ -55,6 +55,8 @@ while time.time() - t0 < budget:
     ctx.set_option("msm_window_bits", wb)
     ctx.set_option("msm_split", int(rng.choice([0, 0, 0, 16, 64])))
     glv = int(rng.choice([1, 1, 0, 2])); ctx.set_option("msm_glv", glv)      # endomorphism split: policy / off / forced
+    for kv in [x for x in os.environ.get("FUZZ_OPTS", "").split(",") if x]:   # e.g. FUZZ_OPTS=msm_dimsum_lanes=16 to bisect a mismatch
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     exp = (cref.msm_g1 if group == 1 else cref.msm_g2)(bases, ss, mixed=True)
     B = ctx.upload_bases(bases, group)
     try:

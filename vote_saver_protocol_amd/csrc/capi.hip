@@ -246,6 +246,20 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
         sc[4 * i] = next(); sc[4 * i + 1] = next(); sc[4 * i + 2] = next(); sc[4 * i + 3] = next() >> 2;     // < 2^254 < r
         if (i >= n && i % 7 == 3) { sc[4 * i] &= 1; sc[4 * i + 1] = sc[4 * i + 2] = sc[4 * i + 3] = 0; }     // zeros and ones among the check's scalars
     }
+    // equal points and opposite points under equal scalars: the same bucket meets P + P (the doubling path of every addition routine, the
+    // equal-x hand-back of the accumulation kernel) and P - P (the infinity paths) in all three pipelines
+    static const uint64_t R64[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    for (size_t i = 1; i < n; i++) {
+        if (i % 16 == 5) for (int j = 0; j < 4; j++) sc[4 * i + j] = sc[4 * (i - 1) + j];                    // the same point twice
+        else if (i % 16 == 9) {                                                                             // a point and its negative: r - k
+            unsigned __int128 borrow = 0;
+            for (int j = 0; j < 4; j++) {
+                const unsigned __int128 d = (unsigned __int128)R64[j] - sc[4 * (i - 1) + j] - borrow;
+                sc[4 * i + j] = (uint64_t)d; borrow = (d >> 64) & 1;
+            }
+        } else continue;
+        for (int j = 0; j < 4; j++) sc[4 * (n + i) + j] = sc[4 * (n + i - 1) + j];                           // ... under the same scalar
+    }
     const size_t esz = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine), row = group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
     void *d_pts = nullptr, *t28 = nullptr;
     bool same = false, ran = false;
