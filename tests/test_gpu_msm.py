@@ -309,6 +309,35 @@ def test_msm_duplicate_bases_take_the_equal_x_path(ctx, cref, precompute):
         ctx.dfree(d_s); B.free()
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_one_point_many_times_in_the_bucket_reduction(ctx, cref, group):
+    """Every base the SAME point, uniform scalars, narrow windows: the bucket sums are small multiples of one point, so the subset sums of
+    the bucket reduction (k_dimsum_mixed, k_dimbits / k_dimweight) keep adding EQUAL points -- the doubling path of the full addition --
+    and opposite ones.  The configuration with which tools/fuzz_msm.py (seed 41) showed a prefetching variant of k_dimsum_mixed to be
+    wrong while the rest of the suite passed; several sizes and window widths around it."""
+    one = (cref.g1_batch_mul_gen if group == 1 else cref.g2_batch_mul_gen)(rand_fr_array(1, seed=91))
+    fn = cref.msm_g1 if group == 1 else cref.msm_g2
+    try:
+        for n, wb in ((34, 8), (34, 0), (200, 5), (200, 11), (1500, 8), (1500, 13), (5000, 0)):
+            bases = np.repeat(one, n, axis=0)
+            ss = rand_fr_array(n, seed=92 + n)
+            if n > 100:
+                bases[n // 2:] = (g1_limbs(o.G1.neg(o.g1_from_limbs(one[0]))) if group == 1 else g2_limbs(o.G2.neg(o.g2_from_limbs(one[0]))))
+            want = fn(bases, ss, mixed=True)
+            ctx.set_option("msm_window_bits", wb)
+            for pre in (False, True):
+                B = ctx.upload_bases(bases, group); d_s = ctx.to_device(ss)
+                try:
+                    if pre:
+                        B.precompute(wb if 8 <= wb <= 16 else 0)
+                    got, _ = B.msm(d_s)
+                    assert np.array_equal(got, want), (n, wb, pre)
+                finally:
+                    B.free(); ctx.dfree(d_s)
+    finally:
+        ctx.set_option("msm_window_bits", 0)
+
+
 def test_msm_pipelined_slots_and_shared_streams(ctx, cref):
     """vsp_msm_launch / vsp_msm_finish_jacobian: several multi-exponentiations in flight on their own streams (G1 and G2
     mixed), finished out of order; results identical to the blocking calls and to the oracle."""
