@@ -90,7 +90,7 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * multi-exponentiation -- a blocking read-back); "msm_sort" (0: by size; 1: never the staged sort of large wide-window problems;
  * 2: the staged sort for every window of 12 bits and more), "msm_wide_windows" (0: never more than 16 bits per window), "msm_fold" (0: 255-bit
  * scalars are not folded to min(k, r - k) where the window width divides 255), "msm_fused_split" (0: the endomorphism split and the digit
- * extraction run as two kernels over the scalars instead of one).
+ * extraction run as two kernels over the scalars instead of one), "msm_fused_scans" (0: the bucket scans take three kernels each).
  *
  * Runtime environment.  Results never depend on it.  GPU_MAX_HW_QUEUES (HIP runtime, read once when the runtime starts; default 4
  * hardware queues per stream priority): one proof's latency does not depend on it (the prover's two chains take their queues when the
