@@ -4,7 +4,9 @@ next bucket record in flight across the current addition) return wrong sums when
    VSP_LIB_PATH=vote_saver_protocol_amd/libvsp_hip_pf1.so [OPTS=msm_fp28=0] python tools/dimsum_prefetch_probe.py
 Measured (round 3): k = 1 (the variant), 2 (s_waitcnt 0 before every addition) and 3 (unconditional next load) fail on "one point" and
 "two points" inputs for every size tried but (34 points, 5-bit windows), on the 28-bit and on the 12 x 32-bit form; k = 5 (the same
-prefetch, the addition called with its operands SWAPPED: tmp = cur; tmp += acc; acc = tmp) passes everything, as does the shipped loop."""
+prefetch, the addition called with its operands SWAPPED: tmp = cur; tmp += acc; acc = tmp) passes everything, as does the shipped loop;
+k = 6 (no prefetch, the summand a named const object) passes; k = 7 (prefetch, explicit copies: sum = acc; sum += cur; acc = sum) fails.
+So: wrong exactly when the record loaded one iteration EARLIER is the addition's second (read-only) operand and stays live through it."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
