@@ -1,4 +1,4 @@
-"""CPU, gloo, world sizes 2 and 4: the sharded multi-exponentiation of the package (vote_saver_protocol_amd/sharded.py)
+"""CPU, gloo, world sizes 2, 4 and 8 (the node size the driver scales to): the sharded multi-exponentiation of the package (vote_saver_protocol_amd/sharded.py)
 through its REAL exchange code -- `ShardedMsm.run` / `.msm`, `TorchExchange.begin` / `.end` over a torch.distributed process group,
 the library's host fold (vsp_fold_jacobian; no GPU needed) -- with a stand-in for the per-rank multi-exponentiation: this container has
 no GPU, so each rank's Jacobian partial sum (144 bytes G1, 288 bytes G2) comes from the oracle over the rank's contiguous chunk.  On
@@ -113,7 +113,7 @@ def cref_r_minus_1():
     return o.int_to_limbs(o.R - 1, 4)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_msm_exchange(tmp_path, world):
     port = 29500 + (os.getpid() % 1000) + world
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
