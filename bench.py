@@ -213,17 +213,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     one_thread = {}
     for src, tag in ((pw, "packed"), (wit, "plain")):
         total = 60
-        for k in range(len(ring) - 1):
-            v.groth16_prove_launch(ring[k], dcs, pk, src, r, s_)
-        t0 = time.perf_counter()
-        last = None
-        for k in range(total):
-            nxt = k + len(ring) - 1
-            v.groth16_prove_launch(ring[nxt % len(ring)], dcs, pk, src, r, s_)
-            last = v.groth16_prove_finish(ring[k % len(ring)])
-        dt3 = time.perf_counter() - t0
-        for k in range(total, total + len(ring) - 1):
-            last = v.groth16_prove_finish(ring[k % len(ring)])
+        dt3, last = prove_ring(v, ring, dcs, pk, src, r, s_, total)
         one_thread[tag] = {"proofs_per_s": total / dt3, "ms_per_proof": dt3 / total * 1e3, "contexts": len(ring),
                            "same_proof": bool(np.array_equal(last[0], pa) and np.array_equal(last[1], pb) and np.array_equal(last[2], pc))}
     for c in ring[n_ctx:]:
@@ -302,11 +292,116 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
         out[f"vote_phase_2p{log_m}_error"] = repr(e)
     ctx.host_unregister(wit)
     kp.free(); dcs.free(); cs.free()
-    # CPU leg on a bounded sample: the oracle's serial generator + prover at 2^14, and the GPU on the same instance
-    lg_s = 14
+    # CPU legs on bounded samples: the oracle's serial generator + prover at 2^14 and at 2^16 (the real circuit's likely size, SURVEY.md
+    # section 0), and the GPU on the same instances, bit for bit
+    for lg_s in (14, 16):
+        out.update(cpu_prove_leg(ctx, v, cref, o, lg_s, tox, r, s_, ni=ni, precompute=precompute))
+    return out
+
+
+
+def prove_ring(v, ring, dcs, pk, src, r, s_, total):
+    """ONE host thread, len(ring) - 1 proofs in flight on a ring of contexts (vsp_groth16_prove_launch / _finish): while proof k is being
+    awaited, proofs k + 1 .. are running.  Returns (seconds for `total` proofs, the last proof)."""
+    depth = len(ring)
+    for k in range(depth - 1):
+        v.groth16_prove_launch(ring[k], dcs, pk, src, r, s_)
+    t0 = time.perf_counter()
+    last = None
+    for k in range(total):
+        nxt = k + depth - 1
+        v.groth16_prove_launch(ring[nxt % depth], dcs, pk, src, r, s_)
+        last = v.groth16_prove_finish(ring[k % depth])
+    dt = time.perf_counter() - t0
+    for k in range(total, total + depth - 1):
+        last = v.groth16_prove_finish(ring[k % depth])
+    return dt, last
+
+
+def bcast_arrays(dist, torch, coll_dev, rank, arrays):
+    """rank 0's list of numpy arrays on every rank (shapes and dtypes first, then the bytes): how the ONE synthetic constraint system of
+    the replica-proving leg reaches the ranks that did not generate it"""
+    meta = [[(a.shape, a.dtype.str) for a in arrays] if rank == 0 else None]
+    dist.broadcast_object_list(meta, src=0)
+    out = []
+    for i, (shape, dt) in enumerate(meta[0]):
+        if rank == 0:
+            t = torch.from_numpy(np.ascontiguousarray(arrays[i]).view(np.uint8).reshape(-1)).to(coll_dev)
+        else:
+            t = torch.empty(int(np.prod(shape)) * np.dtype(dt).itemsize, dtype=torch.uint8, device=coll_dev)
+        dist.broadcast(t, src=0)
+        out.append(arrays[i] if rank == 0 else t.cpu().numpy().view(np.dtype(dt)).reshape(shape).copy())
+    return out
+
+
+def gather_bytes(dist, torch, coll_dev, world, blob):
+    """every rank's `blob` (equal lengths) on every rank: the checker's comparison of the replicas' proofs"""
+    t = torch.from_numpy(np.frombuffer(bytes(blob), np.uint8).copy()).to(coll_dev)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [bytes(x.cpu().numpy().tobytes()) for x in parts]
+
+
+def bench_prove_replicas(make_ctx, v, comm, instance, log_m, total=60, contexts=3, precompute=True):
+    """The other half of BASELINE.json's metric at any N ("prove: replicas"): EVERY rank holds the proving key of the same
+    2^log_m-constraint system resident on its own GPU and proves `total` times from one host thread with `contexts` - 1 proofs in flight,
+    packed witness; value = all ranks' proofs / the slowest rank's time, between two barriers.  No collective on the data path: a proof
+    needs the whole key, and a vote is one proof -- votes are what is spread over the GPUs.
+    make_ctx(): a fresh library context on this rank's GPU.  comm: rank, world, barrier(), allmax(x), bcast(arrays), gather(blob).
+    instance(): rank 0 only -- (num_constraints, num_inputs, num_vars, (A, B, C) CSR triples, witness, toxic waste, r, s)."""
+    rank, world = comm["rank"], comm["world"]
+    if rank == 0:
+        nc, ni, nv, (A, B, Cm), wit, tox, r, s_ = instance()
+        head = np.array([nc, ni, nv], np.uint64)
+        arrays = [head, *A, *B, *Cm, wit, tox, r, s_]
+    else:
+        arrays = None
+    arrays = comm["bcast"](arrays)
+    nc, ni, nv = (int(x) for x in arrays[0])
+    A, B, Cm = tuple(arrays[1:4]), tuple(arrays[4:7]), tuple(arrays[7:10])
+    wit, tox, r, s_ = arrays[10:14]
+    ring = [make_ctx() for _ in range(contexts)]
+    ctx = ring[0]
+    dcs = v.R1CS(ctx, nc, ni, nv, A, B, Cm)
+    t0 = time.perf_counter()
+    kp = v.Keypair(ctx, dcs, tox, precompute=precompute)
+    setup_s = time.perf_counter() - t0
+    pw = v.PackedWitness(wit)
+    ref = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_)              # the blocking entry point, plain witness: what every pipelined proof must equal
+    for c in ring:                                                  # warm every context's workspaces
+        v.groth16_prove_launch(c, dcs, kp.pk, pw, r, s_); v.groth16_prove_finish(c)
+    prove_ring(v, ring, dcs, kp.pk, pw, r, s_, 2 * contexts)
+    comm["barrier"](); t0 = time.perf_counter()
+    dt_local, last = prove_ring(v, ring, dcs, kp.pk, pw, r, s_, total)
+    comm["barrier"]()
+    elapsed = comm["allmax"](time.perf_counter() - t0)
+    same_local = all(np.array_equal(a, b) for a, b in zip(last[:3], ref[:3]))
+    blobs = comm["gather"](bytes(ref[3]) + bytes([1 if same_local else 0]))
+    out = {"proofs_per_s": world * total / elapsed, "ms_per_proof_per_gpu": elapsed / total * 1e3, "n_gpus": world, "proofs_per_gpu": total,
+           "contexts_per_gpu": contexts, "constraints": nc, "log_m": log_m, "key_build_s": setup_s, "key_precomputed": bool(precompute),
+           "key_bytes_per_gpu": int(kp.device_bytes()),
+           "every_rank_same_proof_bytes": bool(all(b == blobs[0] and b[-1] == 1 for b in blobs)),
+           "slowest_rank_s": elapsed, "this_rank_s": dt_local,
+           "mode": "replicas: every rank its own resident key, ONE host thread per rank, %d proofs in flight (vsp_groth16_prove_launch / _finish), packed witness" % (contexts - 1)}
+    proof = ref
+    pub = wit[:ni]
+    parts = {nm: kp.part(nm) for nm in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_ABC_g1")} if rank == 0 else None
+    for c in ring[1:]:
+        c.close()
+    kp.free(); dcs.free()
+    ctx.close()
+    return out, proof, pub, parts
+
+
+def cpu_prove_leg(ctx, v, cref, o, lg_s, tox, r, s_, ni=30, precompute=True):
+    """The reference's prover on the host beside the GPU's, same instance (north_star: the CPU path timed on the same box in the same run):
+    the oracle's serial generator + r1cs_gg_ppzksnark prover at 2^lg_s constraints (a BOUNDED sample of config 4: the 2^20 instance would
+    be ~16x the 2^16 one), then this library on the very same key and witness, bit for bit."""
     nc_s = (1 << lg_s) - ni - 2
     cs2, wit2 = cref.R1CS.synth(nc_s, ni, 4)
+    t0 = time.perf_counter()
     kp = cref.Keypair(cs2, tox)
+    keygen_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     eA, eB, eC = kp.prove(wit2, r, s_)
     cpu_dt = time.perf_counter() - t0
@@ -318,14 +413,17 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
     A2, B2, C2 = cs2.export()
     dcs2 = v.R1CS(ctx, nc_s, ni, cs2.num_vars, A2, B2, C2)
     v.groth16_prove(ctx, dcs2, pk2, wit2, r, s_)
-    t0 = time.perf_counter()
-    gA, gB, gC, _ = v.groth16_prove(ctx, dcs2, pk2, wit2, r, s_)
-    gpu_dt = time.perf_counter() - t0
-    out.update({f"prove_2p{lg_s}_cpu_oracle_s": cpu_dt, f"prove_2p{lg_s}_gpu_ms": gpu_dt * 1e3,
-                f"prove_2p{lg_s}_bit_exact_vs_cpu": bool(np.array_equal(gA, eA) and np.array_equal(gB, eB) and np.array_equal(gC, eC))})
+    each = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        gA, gB, gC, _ = v.groth16_prove(ctx, dcs2, pk2, wit2, r, s_)
+        each.append(time.perf_counter() - t0)
+    gpu_dt = float(np.median(each))
+    out = {f"prove_2p{lg_s}_cpu_oracle_s": cpu_dt, f"prove_2p{lg_s}_cpu_oracle_keygen_s": keygen_s, f"prove_2p{lg_s}_gpu_ms": gpu_dt * 1e3,
+           f"prove_2p{lg_s}_gpu_over_cpu": cpu_dt / gpu_dt,
+           f"prove_2p{lg_s}_bit_exact_vs_cpu": bool(np.array_equal(gA, eA) and np.array_equal(gB, eB) and np.array_equal(gC, eC))}
     pk2.free(); dcs2.free(); [q.free() for q in q2]; kp.free(); cs2.free()
     return out
-
 
 
 def issue_costs():

@@ -335,6 +335,11 @@ int vsp_fixed_base_mul_g2(vsp_ctx *ctx, const void *d_scalars, size_t n, void *d
  * exercise the 14 x 28-bit lazy field of the G1 accumulation (round trip, product, the lazy subtractions and the negation).
  * Lets the tests check the kernels' Montgomery arithmetic directly against known-answer vectors. */
 int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* The full addition of two bucket sums on its own: out[i] = a[i] + b[i], points as canonical (X, Y, ZZ, ZZZ) records with x = X / ZZ,
+ * y = Y / ZZZ, ZZ^3 = ZZZ^2, all-zero = infinity (group 1: 4 x 6 limbs, group 2: 4 x 12 limbs; host buffers).  form 0 = the 12 x 32-bit
+ * formulas, 1 = the 14 x 28-bit lazy form the merges and the bucket reduction run.  The result is some representation of the sum
+ * (compare X / ZZ, Y / ZZZ).  Covers the exceptional cases -- doubling, cancellation, infinity on either side -- lane by lane. */
+int vsp_selftest_xyzz_add(vsp_ctx *ctx, int group, int form, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 
 /* ---- wire format helpers (host only, tiny) ---------------------------------------------------
  * compress: VSP_ERR_ARG for a null pointer or a coordinate that is not canonical (>= p). */

@@ -198,8 +198,21 @@ def madd28(acc, q, negate):
     return (X3, Y3, mm28(ZZ, PP), mm28(ZZZ, PPP)), True
 
 
+def dbl28(a):
+    """fp28.h xyzz_dbl28: the doubling the full addition takes at equal x, equal y (dbl-2008-s-1, a = 0)"""
+    X, Y, ZZ, ZZZ = a
+    U = lin(Y, 2, ZERO, 0)
+    V = mm28(U, U)
+    Wd = mm28(U, V)
+    S = mm28(X, V)
+    M = norm28(lin(sq28(X), 3, ZERO, 0))
+    X3 = norm28(sub28(sq28(M), K["FP28_K8_L4"], lin(S, 2, ZERO, 0)))
+    Y3 = mm28(M, sub28(S, K["FP28_K32_L1"], X3), neg28(K["FP28_K32_L1"], Y), Wd)
+    return (X3, Y3, mm28(V, ZZ), mm28(Wd, ZZZ))
+
+
 def add28(a, b):
-    """fp28.h xyzz_add(XYZZ<Fp28>&, const XYZZ<Fp28>&): (sum, True), or (a, False) where the kernel takes the generic formulas (equal x)."""
+    """fp28.h xyzz_add(XYZZ<Fp28>&, const XYZZ<Fp28>&): (sum, True); at equal x (2 b, False) or (None, False) -- finished in place."""
     if b is None:
         return a, True
     if a is None:
@@ -210,9 +223,9 @@ def add28(a, b):
     S1, S2 = mm28(Y1, ZZZ2), mm28(Y2, ZZZ1)
     Pd = norm28(sub28(U2, K["FP28_K8_L1"], U1))
     PP = sq28(Pd)
-    if is_zero_product(PP, 2):
-        return a, False
     R = norm28(sub28(S2, K["FP28_K8_L1"], S1))
+    if is_zero_product(PP, 2):
+        return (dbl28(b) if is_zero_product(sq28(R), 2) else None), False
     PPP, Q = mm28(Pd, PP), mm28(U1, PP)
     s = lin(PPP, 1, Q, 2)
     X3 = norm28(sub28(sq28(R), K["FP28_K8_L4"], s))
@@ -264,8 +277,25 @@ def madd28_g2(acc, q, negate):
     return (X3, Y3, mulF2(ZZ, PP, K8), mulF2(ZZZ, PPP, K8)), True
 
 
+def dbl28_g2(a):
+    """fp28.h xyzz_dbl28_g2: the doubling over Fp2 on lane pairs"""
+    X, Y, ZZ, ZZZ = a
+    K8, K32, K64L4, K8L4 = (K[n] for n in ("FP28_K8_L1", "FP28_K32_L1", "FP28_K64_L4", "FP28_K8_L4"))
+    Yn = tuple(norm28(c) for c in Y)
+    U = tuple(norm28(lin(c, 2, ZERO, 0)) for c in Yn)
+    V = sqrF2(U, K32)
+    Wd = mulF2(U, V, K8)
+    S = mulF2(X, V, K8)
+    M = tuple(norm28(lin(c, 3, ZERO, 0)) for c in sqrF2(X, K32))
+    X3 = tuple(norm28(sub28(mm, K8L4, lin(ss, 2, ZERO, 0))) for mm, ss in zip(sqrF2(M, K8), S))
+    D = tuple(sub28(ss, K32, x3) for ss, x3 in zip(S, X3))
+    t1, t2 = mulF2(M, D, K64L4), mulF2(Yn, Wd, K8)
+    Y3 = tuple(sub28(x, K8, y) for x, y in zip(t1, t2))
+    return (X3, Y3, mulF2(V, ZZ, K8), mulF2(Wd, ZZZ, K8))
+
+
 def add28_g2(a, b):
-    """fp28.h xyzz_add(XYZZ<Fp28L>&, const XYZZ<Fp28L>&): the full addition over Fp2 on lane pairs; (sum, True) or (a, False) at equal x"""
+    """fp28.h xyzz_add(XYZZ<Fp28L>&, const XYZZ<Fp28L>&): the full addition over Fp2 on lane pairs; (sum, True); at equal x (2 b, False) or (None, False)"""
     if b is None:
         return a, True
     if a is None:
@@ -277,9 +307,9 @@ def add28_g2(a, b):
     S1, S2 = mulF2(Y1, ZZZ2, K8), mulF2(Y2, ZZZ1, K8)
     Pd = tuple(norm28(sub28(u2, K8, u1)) for u2, u1 in zip(U2, U1))
     PP = sqrF2(Pd, K32)
-    if all(is_zero_product(c, 2) for c in PP):
-        return a, False
     R = tuple(norm28(sub28(s2, K8, s1)) for s2, s1 in zip(S2, S1))
+    if all(is_zero_product(c, 2) for c in PP):
+        return (dbl28_g2(b) if all(is_zero_product(c, 2) for c in sqrF2(R, K32)) else None), False
     PPP, Q = mulF2(Pd, PP, K8), mulF2(U1, PP, K8)
     s = tuple(lin(x, 1, y, 2) for x, y in zip(PPP, Q))
     X3 = tuple(norm28(sub28(rr, K8L4, ss)) for rr, ss in zip(sqrF2(R, K32), s))
@@ -403,9 +433,22 @@ def test_exact_model_full_addition_g1():
     total, ref = sums[0]
     assert acc_affine(total) == ref
     assert add28(None, total) == (total, True) and add28(total, None) == (total, True)
-    assert add28(total, total) == (total, False)                                           # doubling
+    dbl, ok = add28(total, total)                                                          # doubling: finished in the 28-bit form
+    assert not ok and acc_affine(dbl) == o.G1.add(ref, ref)
+    assert val(dbl[0]) < 9.5 * P and val(dbl[1]) < 8 * P and val(dbl[2]) < 1.1 * P and val(dbl[3]) < 1.1 * P
+    assert all(x <= MASK for comp in dbl for x in comp[:-1])
     neg = (total[0], norm28(neg28(K["FP28_K32_L1"], total[1])), total[2], total[3])
-    assert add28(total, neg) == (total, False)                                             # cancellation
+    assert add28(total, neg) == (None, False)                                              # cancellation: infinity
+    # the same point in two different representations (what coinciding partial sums look like), and a chain of doublings
+    z = rng.randrange(2, P); zz, zzz = z * z % P, z * z * z % P
+    other = tuple(to28(from28(c) * f % P) for c, f in zip(total, (zz, zzz, zz, zzz)))
+    d2, ok = add28(total, other)
+    assert not ok and acc_affine(d2) == o.G1.add(ref, ref)
+    assert add28(other, neg) == (None, False)
+    cur, rc = total, ref
+    for _ in range(6):
+        cur, ok = add28(cur, cur); rc = o.G1.add(rc, rc)
+        assert not ok and acc_affine(cur) == rc
 
     def lift(x, cap_mult):
         kmax = int(cap_mult * 1000) * P // 1000
@@ -421,6 +464,9 @@ def test_exact_model_full_addition_g1():
         c, ok = add28(worst_state(a), worst_state(b))
         assert ok and acc_affine(c) == o.G1.add(a, b)
         assert val(c[0]) < 9.5 * P and val(c[1]) < 1.5 * P
+        d, ok = add28(worst_state(a), worst_state(a))                                      # doubling at the invariants' worst case
+        assert not ok and acc_affine(d) == o.G1.add(a, a)
+        assert val(d[0]) < 9.5 * P and val(d[1]) < 1.5 * P and val(d[2]) < 1.1 * P and val(d[3]) < 1.1 * P
 
 
 def test_exact_model_random_and_adversarial_g2():
@@ -488,9 +534,22 @@ def test_exact_model_full_addition_g2():
             nxt.append((c, o.G2.add(ra, rb)))
         sums = nxt
     total, ref = sums[0]
-    assert add28_g2(total, total) == (total, False)
+
+    def inside(c):
+        for comp in range(2):
+            assert val(c[0][comp]) < 11.7 * P and val(c[1][comp]) < 10.4 * P and val(c[2][comp]) < 3.9 * P and val(c[3][comp]) < 3.9 * P
+            assert all(x <= MASK for k in (0, 2, 3) for x in c[k][comp][:-1]) and all(x < 1 << 30 for x in c[1][comp][:-1])
+
+    dbl, ok = add28_g2(total, total)
+    assert not ok and acc_affine_g2(dbl) == o.G2.add(ref, ref)
+    inside(dbl)
     neg = (total[0], tuple(norm28(neg28(K["FP28_K32_L4"], c)) for c in total[1]), total[2], total[3])
-    assert add28_g2(total, neg) == (total, False)
+    assert add28_g2(total, neg) == (None, False)
+    cur, rc = total, ref
+    for _ in range(4):
+        cur, ok = add28_g2(cur, cur); rc = o.G2.add(rc, rc)
+        assert not ok and acc_affine_g2(cur) == rc
+        inside(cur)
 
     def lift(x, cap_mult):
         kmax = int(cap_mult * 1000) * P // 1000
@@ -507,6 +566,9 @@ def test_exact_model_full_addition_g2():
     for a, b in zip(pts[:6], pts[6:12]):
         c, ok = add28_g2(worst_state(a), worst_state(b))
         assert ok and acc_affine_g2(c) == o.G2.add(a, b)
+        d, ok = add28_g2(worst_state(a), worst_state(a))                                   # doubling at the invariants' worst case
+        assert not ok and acc_affine_g2(d) == o.G2.add(a, a)
+        inside(d)
 
 
 # ------------------------------------------------------------------------------------------------ worst-case propagation
@@ -601,6 +663,53 @@ def test_invariants_are_inductive_full_addition_g1():
     Y3 = b_mul(R, D, nS1, PPP); assert Y3.v < 1.13 * P
     ZZ3, ZZZ3 = b_mul(b_mul(ZZ, ZZ), PP), b_mul(b_mul(ZZZ, ZZZ), PPP)
     assert ZZ3.v < 1.01 * P and ZZZ3.v < 1.01 * P
+    assert X3.v <= X.v and Y3.v <= Y.v and ZZ3.v <= ZZ.v and ZZZ3.v <= ZZZ.v
+
+
+def test_invariants_are_inductive_doubling_g1():
+    """the invariants on the operand  ==>  the same after xyzz_dbl28 (the equal-x branch of the full addition), and the branch's own
+    zero test (R^2 against {0, p}) is exhaustive"""
+    X, Y, ZZ, ZZZ = B.tight(9.5 * P), B.tight(8 * P + 1), B.tight(1.1 * P), B.tight(1.1 * P)
+    S1 = b_mul(Y, ZZZ)
+    R = b_norm(b_sub(S1, "FP28_K8_L1", S1)); assert b_mul(R, R).v < 2 * P
+    U = b_lin(Y, 2, B(1, [1] * N), 0); assert max(U.l[:-1]) <= 1 << 29
+    V = b_mul(U, U); assert V.v < 1.11 * P
+    Wd, S = b_mul(U, V), b_mul(X, V); assert Wd.v < 1.01 * P and S.v < 1.005 * P
+    M = b_norm(b_lin(b_mul(X, X), 3, B(1, [1] * N), 0)); assert M.v < 3.2 * P
+    X3 = b_norm(b_sub(b_mul(M, M), "FP28_K8_L4", b_lin(S, 2, B(1, [1] * N), 0))); assert X3.v < 9.01 * P
+    D = b_sub(S, "FP28_K32_L1", X3); assert max(D.l[:-1]) <= 1 << 30
+    nY = b_sub(B(1, [1] * N), "FP28_K32_L1", Y); assert max(nY.l[:-1]) <= 1 << 29
+    Y3 = b_mul(M, D, nY, Wd); assert Y3.v < 1.06 * P
+    ZZ3, ZZZ3 = b_mul(V, ZZ), b_mul(Wd, ZZZ)
+    assert X3.v <= X.v and Y3.v <= Y.v and ZZ3.v <= ZZ.v and ZZZ3.v <= ZZZ.v
+
+
+def test_invariants_are_inductive_doubling_g2():
+    """the lane-pair invariants on the operand  ==>  the same after xyzz_dbl28_g2"""
+    def pair_mul(a, b, kb):
+        nb = b_sub(B(1, [1] * N), kb, b)
+        e, od = b_mul(a, b, a, nb), b_mul(a, b, a, b)
+        return e if e.v > od.v else od
+
+    def pair_sqr(a, ka):
+        e, od = b_mul(b_lin(a, 1, a, 1), b_sub(a, ka, a)), b_mul(a, b_lin(a, 2, B(1, [1] * N), 0))
+        return e if e.v > od.v else od
+
+    one = B(1, [1] * N)
+    X, ZZ, ZZZ = B.tight(11.7 * P), B.tight(3.9 * P), B.tight(3.9 * P)
+    Y = B(int(10.4 * P), [1 << 30] * (N - 1) + [(int(10.4 * P) >> (W * (N - 1))) + 1])
+    S1 = pair_mul(Y, ZZZ, "FP28_K8_L1")
+    R = b_norm(b_sub(S1, "FP28_K8_L1", S1)); assert pair_sqr(R, "FP28_K32_L1").v < 2 * P      # zero test against {0, p} exhaustive
+    Yn = b_norm(Y)
+    U = b_norm(b_lin(Yn, 2, one, 0)); assert U.v < 20.9 * P
+    V = pair_sqr(U, "FP28_K32_L1"); assert V.v < 1.9 * P
+    Wd, S = pair_mul(U, V, "FP28_K8_L1"), pair_mul(X, V, "FP28_K8_L1"); assert Wd.v < 1.1 * P and S.v < 1.06 * P
+    M = b_norm(b_lin(pair_sqr(X, "FP28_K32_L1"), 3, one, 0)); assert M.v < 4.3 * P
+    X3 = b_norm(b_sub(pair_sqr(M, "FP28_K8_L1"), "FP28_K8_L4", b_lin(S, 2, one, 0))); assert X3.v < 9.1 * P
+    D = b_sub(S, "FP28_K32_L1", X3); assert max(D.l[:-1]) <= 1 << 30
+    t1, t2 = pair_mul(M, D, "FP28_K64_L4"), pair_mul(Yn, Wd, "FP28_K8_L1")
+    Y3 = b_sub(t1, "FP28_K8_L1", t2); assert Y3.v < 9.2 * P and max(Y3.l[:-1]) <= 1 << 30
+    ZZ3, ZZZ3 = pair_mul(V, ZZ, "FP28_K8_L1"), pair_mul(Wd, ZZZ, "FP28_K8_L1"); assert ZZ3.v < 1.02 * P and ZZZ3.v < 1.02 * P
     assert X3.v <= X.v and Y3.v <= Y.v and ZZ3.v <= ZZ.v and ZZZ3.v <= ZZZ.v
 
 

@@ -73,3 +73,75 @@ def test_fp28_lazy_field_against_big_integers(ctx):
     assert ints(run(ctx, 0, 10, a, b), nl) == [x * (y - x) % mod for x, y in zip(A, B)]
     assert ints(run(ctx, 0, 11, a, b), nl) == [(-y) * x % mod for x, y in zip(A, B)]
     assert ints(run(ctx, 0, 12, a, b), nl) == [(x * (y - x) - y * x) % mod for x, y in zip(A, B)]
+
+
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("form", [0, 1])
+def test_full_addition_of_bucket_sums_lane_by_lane(ctx, group, form):
+    """xyzz_add on its own (vsp_selftest_xyzz_add), 12 x 32-bit and 14 x 28-bit lazy form, G1 and the lane-pair G2: ordinary sums,
+    the SAME point in two different representations (the doubling the round-4 kernels finish in the 28-bit form), a point and its
+    negative, infinity on either side -- interleaved so that the lanes of one wave take different paths -- against the group law
+    in plain integers."""
+    rng = np.random.default_rng(40 + group)
+    G, F = (o.G1, None) if group == 1 else (o.G2, o.Fp2Ops)
+    nl = 6 * group
+    n = 256
+    pts = [G.mul(G.gen, int(rng.integers(1, 1 << 62))) for _ in range(24)]
+
+    def fmul(a, b):
+        return a * b % o.P if group == 1 else F.mul(a, b)
+
+    def rep(pt):                                            # a random representation (x z^2, y z^3, z^2, z^3)
+        if pt is None:
+            return None
+        z = int.from_bytes(rng.bytes(47), "little") + 1
+        z = z if group == 1 else (z, int.from_bytes(rng.bytes(47), "little"))
+        zz = fmul(z, z); zzz = fmul(zz, z)
+        return (fmul(pt[0], zz), fmul(pt[1], zzz), zz, zzz)
+
+    def words(r):
+        if r is None:
+            return [0] * (4 * nl)
+        out = []
+        for c in r:
+            for comp in ((c,) if group == 1 else c):
+                out += [(comp >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+        return out
+
+    A, B, want = [], [], []
+    for i in range(n):
+        p, q = pts[i % 24], pts[(7 * i + 3) % 24]
+        kind = i % 8
+        if kind in (1, 5):
+            q = p                                           # doubling: equal points, different representations
+        elif kind == 2:
+            q = G.neg(p)                                    # cancellation
+        elif kind == 3:
+            p = None
+        elif kind == 4:
+            q = None
+        elif kind == 6 and i % 16 == 6:
+            p = q = None
+        ra, rb = rep(p), rep(q)
+        if kind == 5:
+            rb = ra                                         # doubling of the very same record
+        A.append(words(ra)); B.append(words(rb)); want.append(G.add(p, q))
+    a, b = np.array(A, dtype=np.uint64), np.array(B, dtype=np.uint64)
+    out = np.zeros_like(a)
+    p_ = lambda x: x.ctypes.data_as(C.c_void_p)
+    ctx.check(ctx.lib.vsp_selftest_xyzz_add(ctx.h, group, form, p_(a), p_(b), p_(out), n))
+    bad = []
+    for i in range(n):
+        vals = ints(out[i], 6)
+        comps = vals if group == 1 else [(vals[2 * k], vals[2 * k + 1]) for k in range(4)]
+        X, Y, ZZ, ZZZ = comps
+        zero = (ZZ == 0) if group == 1 else (ZZ == (0, 0))
+        if zero:
+            got = None
+        elif group == 1:
+            got = (X * pow(ZZ, -1, o.P) % o.P, Y * pow(ZZZ, -1, o.P) % o.P)
+        else:
+            got = (F.mul(X, F.inv(ZZ)), F.mul(Y, F.inv(ZZZ)))
+        if got != want[i]:
+            bad.append((i, i % 8))
+    assert not bad, bad[:16]

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "vsp_fixed_base_mul_g1": (_I, [_P, _P, _SZ, _P]),
     "vsp_fixed_base_mul_g2": (_I, [_P, _P, _SZ, _P]),
     "vsp_selftest_field": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),
+    "vsp_selftest_xyzz_add": (_I, [_P, _I, _I, _P, _P, _P, _SZ]),
     "vsp_g1_compress": (_I, [_P, _P]),
     "vsp_g2_compress": (_I, [_P, _P]),
     "vsp_g1_decompress": (_I, [_P, _I, _P, _P]),

@@ -2,6 +2,7 @@
 // witness_map entry points, Jacobian record folding and the ZCash point compression.
 #include "common.h"
 #include "fp28.h"
+#include "lane_view.h"
 
 namespace vsp {
 
@@ -12,7 +13,7 @@ int set_hip_error(vsp_ctx *ctx, hipError_t e, const char *what, const char *file
     return VSP_ERR_HIP;
 }
 int set_error(vsp_ctx *ctx, int code, const char *msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) { ctx->err = msg; ctx->err_code = code; }
     return code;
 }
 int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes) {
@@ -88,6 +89,34 @@ __global__ __launch_bounds__(64) void k_selftest_fp28(int op, const Fp *a, const
 #endif
 }
 
+// The full addition of two bucket sums (curve.h / fp28.h xyzz_add) on its own, in each of the four forms the merges and the bucket
+// reduction run it in (diagnostic entry point vsp_selftest_xyzz_add): canonical X, Y, ZZ, ZZZ in, canonical out.  Lanes of one wave take
+// different paths (ordinary sum, doubling, cancellation, infinity on either side) as the test orders its cases -- the divergence the
+// kernels meet.  form 0: 12 x 32-bit limbs; 1: 14 x 28-bit lazy limbs.  G2 runs on lane pairs (two lanes per point).
+__device__ __forceinline__ Fp &fp_of(Fp &x) { return x; }
+__device__ __forceinline__ Fp &fp_of(Fp2L &x) { return x.v; }
+__device__ __forceinline__ Fp28 &fp28_of(Fp28 &x) { return x; }
+__device__ __forceinline__ Fp28 &fp28_of(Fp28L &x) { return x.v; }
+template <class M, class F28> __global__ __launch_bounds__(64) void k_selftest_xyzz_add(int form, const XYZZ<M> *a, const XYZZ<M> *b, XYZZ<M> *out, size_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using LV = LaneView<M>; using E = typename LV::E; using E28 = typename LaneView<F28>::E;
+    const size_t i = gid<M>();
+    if (i >= n) return;                                           // both lanes of a pair leave together
+    XYZZ<E> x = LV::load(&a[i]), y = LV::load(&b[i]);
+    for (XYZZ<E> *v : {&x, &y}) { fp_of(v->X) = to_mont(fp_of(v->X)); fp_of(v->Y) = to_mont(fp_of(v->Y)); fp_of(v->ZZ) = to_mont(fp_of(v->ZZ)); fp_of(v->ZZZ) = to_mont(fp_of(v->ZZZ)); }
+    if (form == 0) xyzz_add(x, y);
+    else {
+        XYZZ<E28> x28, y28;                                       // zero stays zero: infinity is all-zero in both forms
+        fp28_of(x28.X) = fp_to_fp28(fp_of(x.X)); fp28_of(x28.Y) = fp_to_fp28(fp_of(x.Y)); fp28_of(x28.ZZ) = fp_to_fp28(fp_of(x.ZZ)); fp28_of(x28.ZZZ) = fp_to_fp28(fp_of(x.ZZZ));
+        fp28_of(y28.X) = fp_to_fp28(fp_of(y.X)); fp28_of(y28.Y) = fp_to_fp28(fp_of(y.Y)); fp28_of(y28.ZZ) = fp_to_fp28(fp_of(y.ZZ)); fp28_of(y28.ZZZ) = fp_to_fp28(fp_of(y.ZZZ));
+        xyzz_add(x28, y28);
+        fp_of(x.X) = fp28_to_fp(fp28_of(x28.X)); fp_of(x.Y) = fp28_to_fp(fp28_of(x28.Y)); fp_of(x.ZZ) = fp28_to_fp(fp28_of(x28.ZZ)); fp_of(x.ZZZ) = fp28_to_fp(fp28_of(x28.ZZZ));
+    }
+    fp_of(x.X) = from_mont(fp_of(x.X)); fp_of(x.Y) = from_mont(fp_of(x.Y)); fp_of(x.ZZ) = from_mont(fp_of(x.ZZ)); fp_of(x.ZZZ) = from_mont(fp_of(x.ZZZ));
+    LV::store(&out[i], x);
+#endif
+}
+
 }  // namespace vsp
 
 using namespace vsp;
@@ -108,6 +137,25 @@ int vsp_selftest_field(vsp_ctx *ctx, int field, int op, const uint64_t *a, const
         if (field == 0 && op > 5) hipLaunchKernelGGL(k_selftest_fp28, dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
         else if (field == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fp>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fp *)da.p, (const Fp *)db.p, (Fp *)dc.p, n);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_field<Fr>), dim3(blocks), dim3(64), 0, ctx->stream, op, (const Fr *)da.p, (const Fr *)db.p, (Fr *)dc.p, n);
+        hipMemcpyAsync(out, dc.p, n * esz, hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "selftest: kernel failed");
+    }
+    free_buf(da); free_buf(db); free_buf(dc);
+    return rc;
+}
+
+int vsp_selftest_xyzz_add(vsp_ctx *ctx, int group, int form, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!a || !b || !out || (group != 1 && group != 2) || (form != 0 && form != 1)) return set_error(ctx, VSP_ERR_ARG, "selftest: bad argument");
+    VSP_HIP(hipSetDevice(ctx->device));
+    const size_t esz = group == 1 ? sizeof(XYZZ<Fp>) : sizeof(XYZZ<Fp2>);
+    DevBuf da, db, dc;
+    int rc = ensure(ctx, da, n * esz); if (rc == VSP_OK) rc = ensure(ctx, db, n * esz); if (rc == VSP_OK) rc = ensure(ctx, dc, n * esz);
+    if (rc == VSP_OK) {
+        hipMemcpyAsync(da.p, a, n * esz, hipMemcpyHostToDevice, ctx->stream);
+        hipMemcpyAsync(db.p, b, n * esz, hipMemcpyHostToDevice, ctx->stream);
+        if (group == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_xyzz_add<Fp, Fp28>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, form, (const XYZZ<Fp> *)da.p, (const XYZZ<Fp> *)db.p, (XYZZ<Fp> *)dc.p, n);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selftest_xyzz_add<Fp2, Fp2x28>), dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, ctx->stream, form, (const XYZZ<Fp2> *)da.p, (const XYZZ<Fp2> *)db.p, (XYZZ<Fp2> *)dc.p, n);
         hipMemcpyAsync(out, dc.p, n * esz, hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "selftest: kernel failed");
     }
@@ -231,8 +279,11 @@ int vsp_host_unregister(vsp_ctx *ctx, void *ptr) {
 //       bucket is split in tens of parts), k_dimsum and k_dimbits / k_dimweight -- the default plan;
 //   (b) the same with short bucket parts forced ("msm_split" = 6: every bucket is cut in several parts, the merges' full additions run
 //       thousands of times) and the other last step of the bucket reduction;
-//   (c) through the generic 12 x 32-bit kernels, no split.
-// All three affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0:
+//   (c) through the generic 12 x 32-bit kernels, no split;
+//   (d), (e) the default plan again with 6-bit and with 12-bit windows: other digit splits (q0, q1) of the bucket reduction, other lane counts
+//       per sum in k_dimsum_mixed, and -- the last 512 points being ONE point under 512 different scalars -- bucket sums that coincide all
+//       over the reduction: the doubling branch of the full addition inside k_dimsum(_mixed), k_dimbits and the merges (round 4).
+// All five affine results must be identical.  On a mismatch the 28-bit kernels are switched off for this context ("msm_fp28" = 0:
 // every later multi-exponentiation takes the generic kernels).  Returns true when 28-bit tables may be used.
 static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
     const int gi = group - 1;
@@ -260,10 +311,12 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
         } else continue;
         for (int j = 0; j < 4; j++) sc[4 * (n + i) + j] = sc[4 * (n + i - 1) + j];                           // ... under the same scalar
     }
+    for (size_t i = n - 511; i < n; i++) for (int j = 0; j < 4; j++) sc[4 * i + j] = sc[4 * (n - 512) + j];  // one point 512 times, scalars as drawn
     const size_t esz = group == 1 ? sizeof(G1Affine) : sizeof(G2Affine), row = group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
     void *d_pts = nullptr, *t28 = nullptr;
     bool same = false, ran = false;
     const long saved_split = ctx->opts.count("msm_split") ? ctx->opts["msm_split"] : 0, saved_db = ctx->opts.count("msm_dimbits") ? ctx->opts["msm_dimbits"] : -1;
+    const long saved_wb = ctx->opts.count("msm_window_bits") ? ctx->opts["msm_window_bits"] : 0;
     if (ensure(ctx, ctx->msm_scalars, 2 * n * 32) == VSP_OK && ensure(ctx, ctx->val_flag, 16) == VSP_OK &&
         hipMemcpyAsync(ctx->msm_scalars.p, sc.data(), 2 * n * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
         hipStreamSynchronize(ctx->stream) == hipSuccess && hipMalloc(&d_pts, n * esz) == hipSuccess && hipMalloc(&t28, 2 * n * row) == hipSuccess) {
@@ -274,7 +327,8 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
         if (rc == VSP_OK) rc = group == 1 ? msm_g1_table28(ctx, (const G1Affine *)d_pts, n, t28, true) : msm_g2_table28(ctx, (const G2Affine *)d_pts, n, t28, true);
         if (rc == VSP_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
             ran = true;
-            auto run = [&](const void *table, bool glv, long split, long dimbits, uint64_t *aff, int *inf) -> bool {
+            auto run = [&](const void *table, bool glv, long split, long dimbits, uint64_t *aff, int *inf, long wbits = 0) -> bool {
+                if (wbits) ctx->opts["msm_window_bits"] = wbits; else ctx->opts.erase("msm_window_bits");
                 if (split) ctx->opts["msm_split"] = split; else ctx->opts.erase("msm_split");
                 if (dimbits >= 0) ctx->opts["msm_dimbits"] = dimbits; else ctx->opts.erase("msm_dimbits");
                 if (group == 1) {
@@ -288,14 +342,22 @@ static bool fp28_known_answer_check(vsp_ctx *ctx, int group) {
                 }
                 return true;
             };
-            uint64_t ra[24], rb[24], rc3[24]; int ia = 0, ib = 0, ic = 0;
-            memset(ra, 0, sizeof ra); memset(rb, 0, sizeof rb); memset(rc3, 0, sizeof rc3);
-            const bool okr = run(t28, true, 0, -1, ra, &ia) && run(t28, true, 6, group == 1 ? 0 : 1, rb, &ib) && run(nullptr, false, 0, -1, rc3, &ic);
-            same = okr && ia == ic && ib == ic && !ic && memcmp(ra, rc3, sizeof ra) == 0 && memcmp(rb, rc3, sizeof rb) == 0;
+            uint64_t ra[24], rb[24], rc3[24], rd[24], re[24]; int ia = 0, ib = 0, ic = 0, id = 0, ie = 0;
+            memset(ra, 0, sizeof ra); memset(rb, 0, sizeof rb); memset(rc3, 0, sizeof rc3); memset(rd, 0, sizeof rd); memset(re, 0, sizeof re);
+            const bool okr = run(t28, true, 0, -1, ra, &ia) && run(t28, true, 6, group == 1 ? 0 : 1, rb, &ib) && run(nullptr, false, 0, -1, rc3, &ic) &&
+                             run(t28, true, 0, -1, rd, &id, 6) && run(t28, true, 0, -1, re, &ie, 12);
+            same = okr && ia == ic && ib == ic && id == ic && ie == ic && !ic && memcmp(ra, rc3, sizeof ra) == 0 && memcmp(rb, rc3, sizeof rb) == 0 &&
+                   memcmp(rd, rc3, sizeof rd) == 0 && memcmp(re, rc3, sizeof re) == 0;
+            // which leg differed (stat "msm_fp28_selfcheck_detail_g1/2"): 1 = the default 28-bit pipeline, 2 = the split-bucket / other reduction
+            // pipeline, 4 = a point at infinity where there should be none, 8 = a launch failed, 16 / 32 = the 6-bit / 12-bit window legs
+            ctx->stats[group == 1 ? "msm_fp28_selfcheck_detail_g1" : "msm_fp28_selfcheck_detail_g2"] =
+                (double)((okr ? 0 : 8) | ((ia != ic || memcmp(ra, rc3, sizeof ra)) ? 1 : 0) | ((ib != ic || memcmp(rb, rc3, sizeof rb)) ? 2 : 0) | (ic ? 4 : 0) |
+                         ((id != ic || memcmp(rd, rc3, sizeof rd)) ? 16 : 0) | ((ie != ic || memcmp(re, rc3, sizeof re)) ? 32 : 0));
         }
     }
     if (saved_split) ctx->opts["msm_split"] = saved_split; else ctx->opts.erase("msm_split");
     if (saved_db >= 0) ctx->opts["msm_dimbits"] = saved_db; else ctx->opts.erase("msm_dimbits");
+    if (saved_wb) ctx->opts["msm_window_bits"] = saved_wb; else ctx->opts.erase("msm_window_bits");
     if (d_pts) hipFree(d_pts);
     if (t28) hipFree(t28);
     hipGetLastError();
@@ -327,7 +389,8 @@ static void build_table28(vsp_ctx *ctx, vsp_bases *b, size_t count) {
     b->glv = false;
     long want = 1; { auto it = ctx->opts.find("msm_fp28"); if (it != ctx->opts.end()) want = it->second; }
     long want_glv = 1; { auto it = ctx->opts.find("msm_glv"); if (it != ctx->opts.end()) want_glv = it->second; }
-    if (!want || !fp28_known_answer_check(ctx, b->group)) return;                 // the check may have just switched "msm_fp28" off
+    // "msm_fp28" = 2 (diagnostics: bisecting a failed check with tools/fuzz_msm.py): the 28-bit kernels WITHOUT the context-time check
+    if (!want || (want < 2 && !fp28_known_answer_check(ctx, b->group))) return;   // the check may have just switched "msm_fp28" off
     const size_t row = b->group == 1 ? sizeof(Affine28) : sizeof(Affine28x2);
     bool glv = glv_wanted(ctx, b->group, count, b->pre_c) && (b->in_subgroup > 0 || want_glv >= 2);
     if (b->pre_c && b->pre_split && want_glv && (b->in_subgroup > 0 || want_glv >= 2)) {
@@ -370,7 +433,9 @@ vsp_bases *bases_create(vsp_ctx *ctx, int group, const void *src, bool src_on_de
                             : bases_to_mont_g2(ctx, src, (G2Affine *)b->d, n, (int)check_curve, (uint32_t *)ctx->val_flag.p);
         bool sub_checked = false;
         if (trust == BASES_OWN) b->in_subgroup = 1;
-        else if (rc == VSP_OK && trust == BASES_CALLER && check_curve && (check_sub >= 2 || (check_sub == 1 && glv_wanted(ctx, group, n, 0)))) {
+        // policy 2 covers every upload whose points the library did not make itself (caller's handles, one call's host buffers, key blobs),
+        // with or without the curve check; policy 1 only the uploads that would get the endomorphism layout
+        else if (rc == VSP_OK && (check_sub >= 2 || (trust == BASES_CALLER && check_curve && check_sub == 1 && glv_wanted(ctx, group, n, 0)))) {
             rc = group == 1 ? subgroup_check_g1(ctx, (const G1Affine *)b->d, n, (uint32_t *)ctx->val_flag.p)
                             : subgroup_check_g2(ctx, (const G2Affine *)b->d, n, (uint32_t *)ctx->val_flag.p);
             sub_checked = true;
@@ -456,7 +521,6 @@ static int bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits, bo
             b->in_subgroup = (h_flag & 4u) ? -1 : 1;
             if (h_flag & 4u) ctx->stats["bases_outside_subgroup"] += 1;
         }
-        b->pre_split = true;                                 // (bases outside the subgroup get the ordinary table: build_table28 decides)
     }
     if (window_bits == 0) {                     // automatic: about n * W / 2^(c-1) = 256 points per shared bucket
         unsigned lg = ceil_log2(b->n ? b->n : 1);
@@ -465,7 +529,7 @@ static int bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits, bo
     if (window_bits < 8 || window_bits > 22) return set_error(ctx, VSP_ERR_ARG, "precompute: window_bits must be 8..22");
     if (b->pre_c == window_bits) return VSP_OK;
     if (b->pre_c) return set_error(ctx, VSP_ERR_ARG, "precompute: bases already precomputed for another window size");
-    if (b->n == 0) { b->pre_c = window_bits; return VSP_OK; }
+    if (b->n == 0) { b->pre_c = window_bits; b->pre_split = split; return VSP_OK; }
     VSP_HIP(hipSetDevice(ctx->device));
     const unsigned W = 255 / window_bits + 1;
     const size_t esz = b->group == 1 ? sizeof(G1Affine) : sizeof(G2Affine);
@@ -478,6 +542,7 @@ static int bases_precompute(vsp_ctx *ctx, vsp_bases *b, unsigned window_bits, bo
     VSP_HIP(hipStreamSynchronize(ctx->stream));
     hipFree(b->d);
     b->d = table; b->pre_c = window_bits;
+    b->pre_split = split;                                    // only now: a refused or failed call leaves the handle as it was (bases outside the subgroup get the ordinary table: build_table28 decides)
     build_table28(ctx, b, (size_t)W * b->n);
     return VSP_OK;
 }
@@ -622,7 +687,7 @@ static int msm_host(vsp_ctx *ctx, int group, const uint64_t *bases, const uint64
     if ((!bases || !scalars) && n) return set_error(ctx, VSP_ERR_ARG, "msm: null argument");
     VSP_HIP(hipSetDevice(ctx->device));
     vsp_bases *b = bases_create(ctx, group, bases, false, n, BASES_TRANSIENT);      // one call's bases: no endomorphism split, hence no subgroup check
-    if (!b) return ctx->err.find("hipMalloc") != std::string::npos ? VSP_ERR_NOMEM : VSP_ERR_ARG;
+    if (!b) return ctx->err_code ? ctx->err_code : VSP_ERR_ARG;      // bases_create has said why (set_error)
     int rc = ensure(ctx, ctx->msm_scalars, n * 32);
     if (rc == VSP_OK && n) {
         if (hipMemcpyAsync(ctx->msm_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = set_error(ctx, VSP_ERR_HIP, "msm: H2D of scalars failed");

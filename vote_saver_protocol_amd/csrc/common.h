@@ -97,6 +97,7 @@ struct vsp_ctx {
     hipStream_t prove_streams[2] = {nullptr, nullptr};      // the prover's two witness chains (prover.hip), created on first use
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_aux = nullptr;
     std::string err;
+    int err_code = 0;                   // the code set_error last returned (callers that receive a null handle report it instead of guessing from the text)
     std::map<std::string, double> stats;
     std::map<std::string, long> opts;
     vsp::NttTables ntt;

@@ -194,8 +194,8 @@ __device__ __forceinline__ bool madd28(XYZZ28 &acc, const Affine28 &q, bool nega
 //   PP = P^2 < 1.04p, PPP = P PP, Q = U1 PP < 1.01p,  X3 = R^2 + 8p - (PPP + 2Q) < 9.1p
 //   Y3 = [R (Q + 32p - X3) + (8p - S1) PPP] / 2^392 + p < 1.13p      limb bounds 28+30 and 29+28 as in madd28
 //   ZZ3 = (ZZ1 ZZ2) PP, ZZZ3 = (ZZZ1 ZZZ2) PPP < 1.01p
-// 12 products + 2 squares.  Equal x (P = 0: a doubling or a cancellation -- coinciding partial sums, e.g. duplicated bases) takes the
-// generic 12 x 32-bit formulas through a conversion: rare, and always right.  tests/test_fp28_bounds.py models this function too.
+// 12 products + 2 squares.  Equal x (P = 0: a doubling or a cancellation -- coinciding partial sums, e.g. duplicated bases) is finished
+// in the same form (xyzz_dbl28 below).  tests/test_fp28_bounds.py models this function too.
 __device__ __forceinline__ XYZZ<Fp28> xyzz28_from_fp(const XYZZ<Fp> &a) {
     XYZZ<Fp28> r;
     if (is_inf(a)) return XYZZ<Fp28>::inf();
@@ -208,13 +208,36 @@ __device__ __forceinline__ XYZZ<Fp> xyzz28_to_fp(const XYZZ<Fp28> &a) {
     r.X = fp28_to_fp(a.X); r.Y = fp28_to_fp(a.Y); r.ZZ = fp28_to_fp(a.ZZ); r.ZZZ = fp28_to_fp(a.ZZZ);
     return r;
 }
-// (a real call on memory operands: inlined, the generic formulas crash this toolchain's scheduler next to the product routines; the
-// caller copies its registers into temporaries inside the cold branch, so the hot path keeps everything in registers)
-__device__ __noinline__ void xyzz_add28_equal_x(XYZZ<Fp28> *acc, const XYZZ<Fp28> *q) {
-    XYZZ<Fp> a = xyzz28_to_fp(*acc), b = xyzz28_to_fp(*q);
-    xyzz_add(a, b);
-    *acc = xyzz28_from_fp(a);
+// Doubling in the 28-bit form (dbl-2008-s-1, a = 0), for the equal-x case of the full addition below: the SAME product routines as every
+// other step, so the cold branch is a straight run of register-only routine entries -- no function call, no scratch, no conversion to the
+// 12 x 32-bit form (round 3 took a real call here: DESIGN.md 3.7).  Input under the invariants of the header, output inside them again:
+//   U = 2 Y1 (limbs < 2^29, < 16p),  V = U^2 < 1.11p (29+29),  W = U V < 1.01p,  S = X1 V < 1.005p,
+//   M = 3 X1^2 carried to tight limbs, < 3.2p,  X3 = M^2 + 8p - 2S < 9.01p (tight),
+//   Y3 = [M (S + 32p - X3) + (32p - Y1) W] / 2^392 + p < 1.06p      limb bounds 28+30 and 29+28 as in madd28
+//   ZZ3 = V ZZ1, ZZZ3 = W ZZZ1 < 1.01p.          tests/test_fp28_bounds.py: dbl28 (exact limb model + worst-case states)
+__device__ __forceinline__ XYZZ<Fp28> xyzz_dbl28(const XYZZ<Fp28> &a) {
+    XYZZ<Fp28> r;
+    Fp28 U;
+#pragma unroll
+    for (int i = 0; i < 14; i++) U.l[i] = 2u * a.Y.l[i];
+    Fp28 V = mul28(U, U);
+    Fp28 W = mul28(U, V);
+    Fp28 S = mul28(a.X, V);
+    Fp28 M = sqr28(a.X);
+#pragma unroll
+    for (int i = 0; i < 14; i++) M.l[i] *= 3u;
+    M = norm28(M);
+    Fp28 S2;
+#pragma unroll
+    for (int i = 0; i < 14; i++) S2.l[i] = 2u * S.l[i];
+    r.X = norm28(sub28(sqr28(M), FP28_K8_L4, S2));
+    r.Y = mul28x2(M, sub28(S, FP28_K32_L1, r.X), neg28(FP28_K32_L1, a.Y), W);
+    r.ZZ = mul28(V, a.ZZ);
+    r.ZZZ = mul28(W, a.ZZZ);
+    return r;
 }
+// acc += q, both XYZZ.  Equal x (P = 0: coinciding partial sums -- duplicated bases, a witness of few distinct values) is decided exactly
+// (PP and R^2 are product outputs: zero iff 0 or p) and finished in place: equal y doubles q, opposite y leaves infinity.
 __device__ __forceinline__ void xyzz_add(XYZZ<Fp28> &acc, const XYZZ<Fp28> &q) {
     if (fp28_all_zero(q.ZZ)) return;
     if (fp28_all_zero(acc.ZZ)) { acc = q; return; }
@@ -222,8 +245,11 @@ __device__ __forceinline__ void xyzz_add(XYZZ<Fp28> &acc, const XYZZ<Fp28> &q) {
     Fp28 S1 = mul28(acc.Y, q.ZZZ), S2 = mul28(q.Y, acc.ZZZ);
     Fp28 P = norm28(sub28(U2, FP28_K8_L1, U1));
     Fp28 PP = sqr28(P);
-    if (fp28_product_is_zero(PP)) { XYZZ<Fp28> ta = acc, tq = q; xyzz_add28_equal_x(&ta, &tq); acc = ta; return; }
     Fp28 R = norm28(sub28(S2, FP28_K8_L1, S1));
+    if (fp28_product_is_zero(PP)) {
+        if (fp28_product_is_zero(sqr28(R))) acc = xyzz_dbl28(q); else acc = XYZZ<Fp28>::inf();
+        return;
+    }
     Fp28 PPP = mul28(P, PP);
     Fp28 Q = mul28(U1, PP);
     Fp28 s;
@@ -327,19 +353,38 @@ __device__ __forceinline__ bool madd28_g2(XYZZHalf28 &acc, const AffineHalf28 &q
 //   P = U2 + 8p - U1, R = S2 + 8p - S1: tight after the carry pass, < 9.1p;  PP, RR = squares with K = 32p: (29, 29.6), < 1.3p
 //   PPP = P PP, Q = U1 PP < 1.04p;  X3 = RR + 8p - (PPP + 2Q) < 9.3p;  D = Q + 32p - X3 (limbs < 2^30)
 //   Y3 = R D + 8p - S1 PPP: t1 < 1.36p (28+30, 28+30.3), limbs of Y3 < 2^30, value < 9.4p;  ZZ3, ZZZ3 = two products each, < 1.01p
-// Equal x goes through the generic lane-pair formulas (a real call, see xyzz_add28_equal_x).
+// Equal x is finished in place as on G1: equal y doubles q (xyzz_dbl28_g2), opposite y leaves infinity.
 __device__ __forceinline__ bool is_zero(const Fp28L &a) { return pair_all28(fp28_all_zero(a.v)); }
-__device__ __noinline__ void xyzz_add28_equal_x_g2(XYZZ<Fp28L> *acc, const XYZZ<Fp28L> *q) {
-    auto to_generic = [](const XYZZ<Fp28L> &a) {
-        XYZZ<Fp2L> r = XYZZ<Fp2L>::inf();
-        if (!pair_all28(fp28_all_zero(a.ZZ.v))) { r.X.v = fp28_to_fp(a.X.v); r.Y.v = fp28_to_fp(a.Y.v); r.ZZ.v = fp28_to_fp(a.ZZ.v); r.ZZZ.v = fp28_to_fp(a.ZZZ.v); }
-        return r;
-    };
-    XYZZ<Fp2L> a = to_generic(*acc), b = to_generic(*q);
-    xyzz_add(a, b);
-    XYZZ<Fp28L> r = XYZZ<Fp28L>::inf();
-    if (!is_inf(a)) { r.X.v = fp_to_fp28(a.X.v); r.Y.v = fp_to_fp28(a.Y.v); r.ZZ.v = fp_to_fp28(a.ZZ.v); r.ZZZ.v = fp_to_fp28(a.ZZZ.v); }
-    *acc = r;
+// Doubling over Fp2 on lane pairs (dbl-2008-s-1, a = 0) under the G2 invariants (X tight < 11.7p, Y limbs < 2^30 and < 10.4p, ZZ, ZZZ tight < 3.9p):
+//   Yn = Y carried to tight limbs;  U = 2 Yn carried again (tight, < 20.8p);  V = U^2 with K = 32p (29 + 30) < 1.9p;
+//   W = U V < 1.1p,  S = X1 V < 1.06p;  M = 3 X1^2 (square with K = 32p, < 1.41p each) carried to tight limbs, < 4.3p;
+//   X3 = M^2 + 8p - 2S < 9.1p (tight);  D = S + 32p - X3 (limbs < 2^30);  Y3 = M D + 8p - Yn W: limbs < 2^30, < 9.2p;
+//   ZZ3 = V ZZ1, ZZZ3 = W ZZZ1 < 1.02p.          tests/test_fp28_bounds.py: dbl28_g2
+__device__ __forceinline__ XYZZ<Fp28L> xyzz_dbl28_g2(const XYZZ<Fp28L> &a) {
+    XYZZ<Fp28L> r;
+    Fp28 Yn = norm28(a.Y.v), U;
+#pragma unroll
+    for (int i = 0; i < 14; i++) U.l[i] = 2u * Yn.l[i];
+    U = norm28(U);
+    Fp28 V = sqrF2(U, FP28_K32_L1);
+    Fp28 W = mulF2(U, V, FP28_K8_L1);
+    Fp28 S = mulF2(a.X.v, V, FP28_K8_L1);
+    Fp28 M = sqrF2(a.X.v, FP28_K32_L1);
+#pragma unroll
+    for (int i = 0; i < 14; i++) M.l[i] *= 3u;
+    M = norm28(M);
+    Fp28 S2;
+#pragma unroll
+    for (int i = 0; i < 14; i++) S2.l[i] = 2u * S.l[i];
+    Fp28 X3 = norm28(sub28(sqrF2(M, FP28_K8_L1), FP28_K8_L4, S2));
+    Fp28 D = sub28(S, FP28_K32_L1, X3);
+    Fp28 t1 = mulF2(M, D, FP28_K64_L4);
+    Fp28 t2 = mulF2(Yn, W, FP28_K8_L1);
+    r.X.v = X3;
+    r.Y.v = sub28(t1, FP28_K8_L1, t2);
+    r.ZZ.v = mulF2(V, a.ZZ.v, FP28_K8_L1);
+    r.ZZZ.v = mulF2(W, a.ZZZ.v, FP28_K8_L1);
+    return r;
 }
 __device__ __forceinline__ void xyzz_add(XYZZ<Fp28L> &acc, const XYZZ<Fp28L> &q) {
     if (pair_all28(fp28_all_zero(q.ZZ.v))) return;
@@ -348,8 +393,11 @@ __device__ __forceinline__ void xyzz_add(XYZZ<Fp28L> &acc, const XYZZ<Fp28L> &q)
     Fp28 S1 = mulF2(acc.Y.v, q.ZZZ.v, FP28_K8_L1), S2 = mulF2(q.Y.v, acc.ZZZ.v, FP28_K8_L1);
     Fp28 P = norm28(sub28(U2, FP28_K8_L1, U1));
     Fp28 PP = sqrF2(P, FP28_K32_L1);
-    if (pair_all28(fp28_product_is_zero(PP))) { XYZZ<Fp28L> ta = acc, tq = q; xyzz_add28_equal_x_g2(&ta, &tq); acc = ta; return; }
     Fp28 R = norm28(sub28(S2, FP28_K8_L1, S1));
+    if (pair_all28(fp28_product_is_zero(PP))) {
+        if (pair_all28(fp28_product_is_zero(sqrF2(R, FP28_K32_L1)))) acc = xyzz_dbl28_g2(q); else acc = XYZZ<Fp28L>::inf();
+        return;
+    }
     Fp28 PPP = mulF2(P, PP, FP28_K8_L1);
     Fp28 Q = mulF2(U1, PP, FP28_K8_L1);
     Fp28 s;
