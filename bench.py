@@ -627,6 +627,51 @@ def run_sharded(problem, steps, warmup, exchange, barrier, depth):
     return time.perf_counter() - t0, res
 
 
+def replica_leg(args, v, torch, dist, coll_dev, rank, world, dev_index, barrier, allmax, cref, o):
+    """bench_prove_replicas wired to torch.distributed; rank 0 adds the pairing check of the proof and the CPU prover's time on a bounded sample"""
+    comm = {"rank": rank, "world": world, "barrier": barrier, "allmax": allmax,
+            "bcast": lambda arrays: bcast_arrays(dist, torch, coll_dev, rank, arrays),
+            "gather": lambda blob: gather_bytes(dist, torch, coll_dev, world, blob)}
+    ni = 30
+    nc = (1 << args.prove_log_n) - ni - 2
+
+    def instance():
+        gen = o.splitmix64(5)
+        cs, wit = cref.R1CS.synth(nc, ni, 4, ballot=(25, 7))
+        tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
+        r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
+        trip = cs.export(); nv = cs.num_vars; cs.free()
+        return nc, ni, nv, trip, wit, tox, r, s_
+
+    res, proof, pub, parts = bench_prove_replicas(lambda: v.Context(dev_index), v, comm, instance, args.prove_log_n)
+    if rank == 0:
+        try:
+            import pairing as pg
+            vk = dict(alpha_g1=o.g1_from_limbs(parts["alpha_g1"][0]), beta_g2=o.g2_from_limbs(parts["beta_g2"][0]), gamma_g2=o.g2_from_limbs(parts["gamma_g2"][0]),
+                      delta_g2=o.g2_from_limbs(parts["delta_g2"][0]), gamma_ABC_g1=[o.g1_from_limbs(x) for x in parts["gamma_ABC_g1"]])
+            res["pairing_verified"] = bool(pg.groth16_verify(vk, [int(x) for x in to_ints(pub).tolist()],
+                                                             (o.g1_from_limbs(proof[0]), o.g2_from_limbs(proof[1]), o.g1_from_limbs(proof[2]))))
+        except Exception as e:                             # the checker must not take the line down
+            res["pairing_error"] = repr(e)
+        if not args.no_cpu_baseline:
+            # the reference's prover on this box's host, bounded sample (2^16 constraints, the real circuit's likely size), and this library on the same instance
+            try:
+                c0 = v.Context(dev_index)
+                gen = o.splitmix64(5)
+                tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
+                r = limbs(o.rand_fr(gen), 4); s_ = limbs(o.rand_fr(gen), 4)
+                leg = cpu_prove_leg(c0, v, cref, o, 16, tox, r, s_)
+                c0.close()
+                res["cpu_baseline"] = {"value": 1.0 / leg["prove_2p16_cpu_oracle_s"], "unit": "proofs/s", "cores": 1, "kind": "port",
+                                       "sample": "one proof of a 2^16-constraint instance by the oracle's serial r1cs_gg_ppzksnark prover (oracle/vsp_ref.c), %.2f s; "
+                                                 "the same instance on one GPU: %.2f ms, bit-exact: %s" % (leg["prove_2p16_cpu_oracle_s"], leg["prove_2p16_gpu_ms"], leg["prove_2p16_bit_exact_vs_cpu"]),
+                                       **leg}
+            except Exception as e:
+                res["cpu_baseline_error"] = repr(e)
+    barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1061,6 +1106,12 @@ def main():
     head.bases.free()
     del d_s
 
+    # =============================================================== proofs/s at N > 1: replica proving, every rank its own resident key
+    # (N = 1: bench_prove above measures the same ring mode -- ONE host thread, three contexts, packed witness -- and much more)
+    replicas = None
+    if world > 1 and not args.no_prove:
+        replicas = replica_leg(args, v, torch, dist, coll_dev, rank, world, dev_index, barrier, allmax, cref, o)
+
     # =============================================================== BASELINE config 5 in the same run: 2^26 G1 + 2^24 G2 over the ranks
     if not args.no_config5 and not (world == 1 and args.no_extras):
         c5 = {"scaling": "strong", "n_gpus": world, "msms_in_flight": depth}
@@ -1124,9 +1175,15 @@ def main():
                                  "verified": bool(c5["g1"]["verified"] and c5["g2"]["verified"]) if rank == 0 else None,
                                  "ranks_seen_by_rccl": ranks_seen if exchange.backend == "nccl" else None,
                                  "ranks_seen_by_collective": ranks_seen, "backend": exchange.backend, "n_gpus": world}
+    if replicas is not None:                         # N > 1: the other half of BASELINE.json's metric from the replica leg
+        out["secondary"] = {"metric": "Groth16 proofs/sec at 2^%d constraints (synthetic SAVER-shaped R1CS, pairing-verified), all GPUs" % args.prove_log_n,
+                            "value": replicas["proofs_per_s"], "unit": "proofs/s", "n_gpus": world, "mode": replicas["mode"],
+                            "per_gpu_proofs_per_s": replicas["proofs_per_s"] / world, "every_rank_same_proof_bytes": replicas["every_rank_same_proof_bytes"],
+                            "pairing_verified": replicas.get("pairing_verified"), "cpu_baseline": replicas.get("cpu_baseline")}
+        extras["prove_replicas"] = replicas
     if extras:
         out["extras"] = extras
-        if "prove_2p20_proofs_per_s" in extras:      # the other half of BASELINE.json's metric, same run
+        if replicas is None and "prove_2p20_proofs_per_s" in extras:      # the other half of BASELINE.json's metric, same run
             ot = extras.get("prove_2p20_one_thread_pipelined", {}).get("packed")
             out["secondary"] = {"metric": "Groth16 proofs/sec at 2^20 constraints (synthetic SAVER-shaped R1CS, pairing-verified)",
                                 "value": ot["proofs_per_s"] if ot else extras.get("prove_2p20_two_contexts_proofs_per_s", extras["prove_2p20_proofs_per_s"]), "unit": "proofs/s",

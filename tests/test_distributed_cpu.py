@@ -131,3 +131,105 @@ def test_local_exchange_is_the_same_code_path_without_a_collective():
     bases = cref.g1_batch_mul_gen(ks)
     job = v.ShardedMsm(OracleShard(1, bases, 0), v.LocalExchange(None))
     assert np.array_equal(job.run(ss, 4, 3), cref.msm_g1(bases, ss)) and np.array_equal(job.msm(ss), cref.msm_g1(bases, ss))
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's replica-proving leg (N > 1)
+class _FakeProver:
+    """stand-in for the package in bench.bench_prove_replicas: contexts, a constraint system, a key, launch / finish -- the "proof" is a
+    digest of everything the rank received (constraint system, witness, toxic waste, r, s), so equal proof bytes on every rank prove the
+    broadcast delivered the same instance, and the launch / finish bookkeeping checks the ring discipline (at most one proof in flight per
+    context, every launch finished exactly once)"""
+
+    def __init__(self):
+        import hashlib
+        self.hashlib = hashlib
+        self.launched = self.finished = 0
+        outer = self
+
+        class Context:
+            def __init__(self): self.in_flight = None; self.closed = False
+            def close(self): assert self.in_flight is None; self.closed = True
+        class R1CS:
+            def __init__(self, ctx, nc, ni, nv, A, B, C):
+                h = outer.hashlib.sha256(np.array([nc, ni, nv], np.uint64).tobytes())
+                for trip in (A, B, C):
+                    for a in trip: h.update(np.ascontiguousarray(a).tobytes())
+                self.digest = h.digest()
+            def free(self): pass
+        class Keypair:
+            def __init__(self, ctx, dcs, tox, precompute=True):
+                self.pk = outer.hashlib.sha256(dcs.digest + np.ascontiguousarray(tox).tobytes()).digest()
+            def device_bytes(self): return 12345
+            def part(self, name): return np.zeros((1, 12), np.uint64)
+            def free(self): pass
+        class PackedWitness:
+            def __init__(self, wit): self.raw = np.ascontiguousarray(wit).tobytes(); self.nbytes = len(self.raw) // 8
+        self.Context, self.R1CS, self.Keypair, self.PackedWitness = Context, R1CS, Keypair, PackedWitness
+
+    def _proof(self, pk, src, r, s):
+        raw = src.raw if hasattr(src, "raw") else np.ascontiguousarray(src).tobytes()
+        d = self.hashlib.sha256(pk + raw + np.ascontiguousarray(r).tobytes() + np.ascontiguousarray(s).tobytes()).digest()
+        blob = (d * 6)[:192]
+        w = np.frombuffer(blob, np.uint64)
+        return w[:12].copy(), w[:24].copy(), w[12:24].copy(), blob
+
+    def groth16_prove(self, ctx, dcs, pk, wit, r, s):
+        assert ctx.in_flight is None
+        return self._proof(pk, wit, r, s)
+
+    def groth16_prove_launch(self, ctx, dcs, pk, src, r, s):
+        assert ctx.in_flight is None, "two proofs in flight on one context"
+        ctx.in_flight = self._proof(pk, src, r, s); self.launched += 1
+
+    def groth16_prove_finish(self, ctx):
+        assert ctx.in_flight is not None, "finish without launch"
+        out, ctx.in_flight = ctx.in_flight, None; self.finished += 1
+        return out
+
+
+def _replica_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib.util, json
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cpu = torch.device("cpu")
+
+    def allmax(x):
+        t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); return float(t.item())
+    comm = {"rank": rank, "world": world, "barrier": dist.barrier, "allmax": allmax,
+            "bcast": lambda arrays: bench.bcast_arrays(dist, torch, cpu, rank, arrays),
+            "gather": lambda blob: bench.gather_bytes(dist, torch, cpu, world, blob)}
+
+    def instance():                                              # rank 0 only: the other ranks must get it through the broadcast
+        assert rank == 0
+        rng = np.random.default_rng(99)
+        nc, ni = 500, 30
+        trip = tuple((np.arange(nc + 1, dtype=np.uint32), rng.integers(0, nc, nc, dtype=np.uint32), rng.integers(0, 1 << 63, (nc, 4), dtype=np.uint64)) for _ in range(3))
+        return nc, ni, nc + ni, trip, rng.integers(0, 1 << 63, (nc + ni, 4), dtype=np.uint64), rng.integers(0, 1 << 63, (5, 4), dtype=np.uint64), \
+            rng.integers(0, 1 << 63, 4, dtype=np.uint64), rng.integers(0, 1 << 63, 4, dtype=np.uint64)
+
+    fake = _FakeProver()
+    ctxs = []
+    def make_ctx():
+        c = fake.Context(); ctxs.append(c); return c
+    res, proof, pub, parts = bench.bench_prove_replicas(make_ctx, fake, comm, instance, 9, total=11, contexts=3)
+    ok = (res["n_gpus"] == world and res["proofs_per_gpu"] == 11 and res["every_rank_same_proof_bytes"] and res["proofs_per_s"] > 0
+          and res["constraints"] == 500 and fake.launched == fake.finished == 3 + (2 * 3 + 2) + (11 + 2) and all(c.closed for c in ctxs) and len(ctxs) == 3
+          and pub.shape == (30, 4) and (parts is not None) == (rank == 0))
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "FAIL: " + json.dumps({k: (x if isinstance(x, (int, float, bool, str)) else str(x)) for k, x in res.items()}) + f" launched {fake.launched} finished {fake.finished}")
+    dist.destroy_process_group()
+
+
+def test_replica_proving_leg_of_the_bench_at_world_2(tmp_path):
+    """bench.py --gpus N, N > 1: every rank proves over its own key (bench_prove_replicas) -- here with a stand-in prover over gloo: the instance
+    reaches every rank through the broadcast, the ring keeps one proof in flight per context, the line carries all ranks' proofs / the slowest
+    rank's time, and the ranks' proof bytes are compared"""
+    world = 2
+    port = 29500 + (os.getpid() % 1000) + 17
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
