@@ -220,6 +220,34 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
         c.close()
     for c in extra_ctx:
         c.close()
+    # ---- key memory: the same proofs over a PLAIN key -- no table of window multiples; the 28-bit copy keeps the endomorphism
+    #      image beside every point (1.3 GB at 2^20 against 19 GB) -- latency, the ring's throughput, bytes resident
+    plain = {}
+    try:
+        t0 = time.perf_counter(); kp_plain = v.Keypair(ctx, dcs, tox, precompute=False); plain_setup = time.perf_counter() - t0
+        ring_all = [ctx, v.Context(ctx.device), v.Context(ctx.device)]
+        for c in ring_all:
+            v.groth16_prove(c, dcs, kp_plain.pk, wit, r, s_)
+        tpl = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); got = v.groth16_prove(ctx, dcs, kp_plain.pk, wit, r, s_); tpl.append(time.perf_counter() - t0)
+        dtp, lastp = prove_ring(v, ring_all, dcs, kp_plain.pk, pw, r, s_, 60)
+        dense_p = ctx.host_register(rand_fr(cs.num_vars, 99))
+        v.groth16_prove(ctx, dcs, kp_plain.pk, dense_p, r, s_)
+        tdp = []
+        for _ in range(5):
+            t0 = time.perf_counter(); v.groth16_prove(ctx, dcs, kp_plain.pk, dense_p, r, s_); tdp.append(time.perf_counter() - t0)
+        ctx.host_unregister(dense_p); del dense_p
+        plain = {f"prove_2p{log_m}_plain_key_ms": float(np.median(tpl)) * 1e3, f"prove_2p{log_m}_plain_key_bytes": int(kp_plain.device_bytes()),
+                 f"prove_2p{log_m}_plain_key_proofs_per_s": 60 / dtp, f"prove_2p{log_m}_plain_key_build_s": plain_setup,
+                 f"prove_2p{log_m}_plain_key_dense_witness_ms": float(np.median(tdp)) * 1e3,
+                 f"prove_2p{log_m}_plain_key_same_proof": bool(np.array_equal(got[0], pa) and np.array_equal(got[1], pb) and np.array_equal(got[2], pc)
+                                                               and np.array_equal(lastp[0], pa) and np.array_equal(lastp[2], pc))}
+        for c in ring_all[1:]:
+            c.close()
+        kp_plain.free()
+    except Exception as e:                         # secondary measurement: never take the bench line down
+        plain = {f"prove_2p{log_m}_plain_key_error": repr(e)}
     # ---- the same prover on a DENSE witness (every wire a uniform field element: no zeros, no ones -- the all-ones bucket and the small windows
     #      of a boolean witness are gone, every witness multi-exponentiation is a full-width one).  Not a satisfying assignment: timing only.
     dense = ctx.host_register(rand_fr(cs.num_vars, 99))
@@ -248,7 +276,7 @@ def bench_prove(ctx, v, cref, o, dev, torch, log_m, precompute=True):
               delta_g2=o.g2_from_limbs(delta_g2), gamma_ABC_g1=[o.g1_from_limbs(x) for x in gamma_abc])
     pub = [int(x) for x in to_ints(wit[:ni]).tolist()]
     ok = pg.groth16_verify(vk, pub, (o.g1_from_limbs(pa), o.g2_from_limbs(pb), o.g1_from_limbs(pc)))
-    out = {f"prove_2p{log_m}_dense_witness_ms": dense_ms, f"prove_2p{log_m}_key_bytes": int(key_bytes), **pk_load,
+    out = {f"prove_2p{log_m}_dense_witness_ms": dense_ms, f"prove_2p{log_m}_key_bytes": int(key_bytes), **pk_load, **plain,
            f"prove_2p{log_m}_packed_witness_ms": packed_ms, f"prove_2p{log_m}_packed_witness_same_proof": packed_same,
            f"prove_2p{log_m}_witness_pack_host_ms": pack_ms, f"prove_2p{log_m}_packed_witness_bytes": int(pw.nbytes), f"prove_2p{log_m}_plain_witness_bytes": int(wit.nbytes),
            f"prove_2p{log_m}_one_thread_pipelined": one_thread,
@@ -443,6 +471,24 @@ def issue_costs():
     return out, src
 
 
+def accum_loop_measured_cycles():
+    """the generated accumulation loop on L1-resident / gathered rows, THREE waves per SIMD as the kernel runs (tools/ubench_madd28.hip, committed
+    output): cycles of a SIMD per mixed addition of a wave -- a floor the kernel has been SEEN at, so the ceiling of roofline_valu is never above it"""
+    import re
+    best, src = None, None
+    for f in ("r4_ubench_madd28.txt", "r3_ubench_madd28.txt"):
+        try:
+            for line in open(os.path.join(ROOT, "profiles", f)):
+                m = re.match(r"accum28 asm loop.*?3 wave/SIMD:.*?->\s+(\d+) cycles of a SIMD per wave-op", line)
+                if m and (best is None or int(m.group(1)) < best):
+                    best, src = int(m.group(1)), "profiles/" + f
+        except OSError:
+            continue
+        if best is not None:
+            break
+    return best, src
+
+
 def accum_instr_mix():
     """the instruction mix of ONE iteration (one mixed addition) of the generated G1 accumulation loop, counted from the generator's own
     instruction list (tools/gen_accum28_asm.py): multiply-adds, other VALU, SALU, VMEM"""
@@ -492,7 +538,27 @@ def diag_clock_ghz(dev_index, d_bases_canon, n, d_scalars_ptr, seconds=2.0):
             k += 1
         rc = lib.vsp_diag_clock(ctx, 0, C.byref(ghz), C.byref(waves))
         lib.vsp_bases_free(ctx, b)
-        return {"ghz": ghz.value, "waves_stamped": waves.value, "msms": k, "seconds": time.perf_counter() - t0} if rc == 0 and ghz.value > 0 else None
+        info = {"ghz": ghz.value, "waves_stamped": waves.value, "msms": k, "seconds": time.perf_counter() - t0} if rc == 0 and ghz.value > 0 else None
+        # the same for the passes of the 2^22 transform (k_ntt29_pass stamps a whole pass per wave): 1 s of back-to-back forward transforms
+        try:
+            for name in ("vsp_dmalloc", "vsp_dfree", "vsp_ntt_fr_device", "vsp_diag_clock_ntt"):
+                fn = getattr(lib, name); fn.restype, fn.argtypes = _lib.PROTOTYPES[name]
+            lg = 22
+            d_a = lib.vsp_dmalloc(ctx, (1 << lg) * 32)
+            if d_a and info is not None:
+                for _ in range(2):
+                    lib.vsp_ntt_fr_device(ctx, C.c_void_p(d_a), lg, 0, None)
+                g2, w2 = C.c_double(0), C.c_double(0)
+                lib.vsp_diag_clock_ntt(ctx, 1, C.byref(g2), C.byref(w2))
+                t1, k2 = time.perf_counter(), 0
+                while time.perf_counter() - t1 < seconds / 2:
+                    lib.vsp_ntt_fr_device(ctx, C.c_void_p(d_a), lg, 0, None); k2 += 1
+                if lib.vsp_diag_clock_ntt(ctx, 0, C.byref(g2), C.byref(w2)) == 0 and g2.value > 0:
+                    info["ntt_ghz"] = g2.value; info["ntt_waves_stamped"] = w2.value; info["ntt_transforms"] = k2
+                lib.vsp_dfree(ctx, C.c_void_p(d_a))
+        except Exception as e:                                   # a diagnostic: never take the line down
+            print("bench.py: NTT clock leg failed: %r" % (e,), file=sys.stderr)
+        return info
     finally:
         lib.vsp_destroy(ctx)
 
@@ -875,14 +941,18 @@ def main():
         wave_adds_per_simd = adds * (2 if group == 2 else 1) / 64.0 / N_SIMD          # G2: two lanes per point
         if group == 1:
             mix = accum_instr_mix()
-            ideal_cycles = mix["v_mad_u64_u32"] * costs["mad"] + mix["valu_other"] * costs["simple"]
+            model_cycles = mix["v_mad_u64_u32"] * costs["mad"] + mix["valu_other"] * costs["simple"]
+            seen_cycles, seen_src = accum_loop_measured_cycles()
+            ideal_cycles = min(model_cycles, seen_cycles) if seen_cycles else model_cycles      # a ceiling the kernel cannot beat: the lower of model and measurement
         else:
             mix = {"v_mad_u64_u32": MADS_PER_ADD[2] // 2, "valu_other": None, "note": "per lane of a pair; the rest of the compiler-allocated loop is not priced (a looser peak)"}
-            ideal_cycles = mix["v_mad_u64_u32"] * costs["mad"]
+            ideal_cycles = model_cycles = mix["v_mad_u64_u32"] * costs["mad"]
+            seen_cycles, seen_src = None, None
         clk = clock_info["ghz"] if clock_info else None
         kernel_cycles = (excl_ms * 1e-3 * clk * 1e9 / wave_adds_per_simd) if clk else None
         rv = {"bound": "VALU issue (one wave-instruction per SIMD every 4.6 cycles for v_mad_u64_u32, 2.9 for simple 32-bit ops)", "kernel": rl["kernel"],
               "unit": "shader cycles of a SIMD per mixed addition of a wave", "peak": ideal_cycles, "achieved": kernel_cycles,
+              "peak_instruction_mix_model": model_cycles, "peak_measured_loop_three_waves": seen_cycles, "peak_measured_source": seen_src,
               "frac": (ideal_cycles / kernel_cycles) if kernel_cycles else None,
               "instr_mix": mix, "issue_cycles_per_wave_instruction": costs, "issue_cost_source": cost_src,
               "clock_ghz_in_kernel": clk, "clock_source": ("libvsp_hip_diag.so: delta s_memtime / delta s_memrealtime x 100 MHz around the loop, summed over %d waves of %d "
@@ -1035,6 +1105,20 @@ def main():
                 dom.fft_device(a, inverse=True)
             ctx.synchronize()
             extras["ntt_2p22_inverse_ms"] = (time.perf_counter() - tn) / reps * 1e3
+            ntt_clk = (clock_info or {}).get("ntt_ghz") or (clock_info["ghz"] if clock_info else 2.1)
+            ntt_clk_src = ("libvsp_hip_diag.so: s_memtime / s_memrealtime around every pass of k_ntt29_pass, %d waves of %d transforms in this run" % (clock_info["ntt_waves_stamped"], clock_info["ntt_transforms"])
+                           if (clock_info or {}).get("ntt_ghz") else "the accumulation loop's clock of this run (the transform's own stamp is absent)")
+            if not args.no_cpu_baseline:
+                # BASELINE config 3 beside its CPU figure: the oracle's serial radix-2 transform (libfqfft-lineage basic_radix2_domain, oracle/vsp_ref.c) on the same input
+                a_host = rand_fr(1 << lg, 7)
+                tc = time.perf_counter(); ref_fft = cref.ntt_fr(a_host); cpu_ntt_s = time.perf_counter() - tc
+                d_chk = torch.from_numpy(a_host.view(np.int64)).to(dev)
+                dom.fft_device(d_chk); ctx.synchronize()
+                extras["ntt_2p22_cpu_s"] = cpu_ntt_s
+                extras["ntt_2p22_cpu_baseline"] = {"value": (1 << lg) / cpu_ntt_s, "unit": "elements/s", "cores": 1, "kind": "port",
+                                                   "sample": "one 2^22 forward transform by the oracle's serial radix-2 FFT, %.2f s" % cpu_ntt_s,
+                                                   "matches_gpu_result": bool(np.array_equal(d_chk.cpu().numpy().view(np.uint64).reshape(-1, 4), ref_fft))}
+                del a_host, ref_fft, d_chk
             # algorithmic bytes = 64 B per element for the whole transform (one ideal read + write); the kernel makes
             # `passes` round trips through HBM: the first reads 32 B and writes 36 B per element (lazy 9 x 29-bit limbs), the middle ones
             # read and write 36 B, the last reads 36 B and writes 32 B
@@ -1046,14 +1130,14 @@ def main():
                                            "achieved": (1 << lg) * 64 / dtn / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": (1 << lg) * 64 / dtn / 1e9 / 8000.0,
                                            "passes": npass, "actual_bytes_moved": moved, "butterflies_on_29_bit_limbs": f29,
                                            "valu_mads_per_element": mads / (1 << lg),
-                                           "valu_frac_of_mad_issue_peak": (mads / 64.0 / N_SIMD * issue_costs()[0]["mad"]) / (dtn * (clock_info["ghz"] if clock_info else 2.1) * 1e9),
-                                           "valu_frac_note": "multiply-adds alone at the SIMD's issue cost (profiles/r3_ubench_issue.txt) over the transform's cycles at the clock "
-                                                             "the accumulation loop held in this run (the transform's own in-kernel clock is not stamped)",
+                                           "valu_frac_of_mad_issue_peak": (mads / 64.0 / N_SIMD * issue_costs()[0]["mad"]) / (dtn * ntt_clk * 1e9),
+                                           "clock_ghz_in_kernel": ntt_clk, "clock_source": ntt_clk_src,
+                                           "valu_frac_note": "multiply-adds alone at the SIMD's issue cost (profiles/r3_ubench_issue.txt) over the transform's cycles at clock_ghz_in_kernel",
                                            # the whole instruction stream (disassembly of k_ntt29_pass): a radix-4 butterfly = 4 products of 162 mads + 46
                                            # simple instructions, + ~400 simple ones around them; per element of the last pass one more product + ~150; ~100 per element and pass
                                            "valu_frac_of_instruction_mix_peak": ((((1 << lg) / 4.0) * (lg / 2.0) * (4 * (162 * issue_costs()[0]["mad"] + 46 * issue_costs()[0]["simple"]) + 400 * issue_costs()[0]["simple"])
                                                                                   + (1 << lg) * (162 * issue_costs()[0]["mad"] + (46 + 150 + 100 * npass) * issue_costs()[0]["simple"])) / 64.0 / N_SIMD)
-                                                                                / (dtn * (clock_info["ghz"] if clock_info else 2.1) * 1e9) if f29 else None,
+                                                                                / (dtn * ntt_clk * 1e9) if f29 else None,
                                            "knock_out_timings_ms": {"as_built": 0.60, "products_replaced_by_additions": 0.37, "no_twiddle_loads": 0.52, "no_step_barriers": 0.59,
                                                                     "note": "2^22 forward, round 3 (variant builds, not shipped): the time is memory side + products, not their maximum -- DESIGN.md 3.2"},
                                            "note": "integer-VALU bound: 11 Fr products per element (22 stages as radix-4 steps); the mads alone are a third of the "

@@ -103,6 +103,8 @@ int vsp_set_option(vsp_ctx *ctx, const char *name, long value);
  * accumulation loop -- in the shipped library no stamp executes and this returns VSP_ERR_UNSUPPORTED): the clock the chip held inside
  * that loop since the last reset, delta s_memtime / delta s_memrealtime x 100 MHz summed over waves, and the number of waves. */
 int vsp_diag_clock(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out);
+/* The same for the passes of the radix-2 transform on 29-bit limbs (k_ntt29_pass; stamps around a whole pass of every wave). */
+int vsp_diag_clock_ntt(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out);
 
 /* ---- raw device memory helpers (for callers without torch) --------------------------------- */
 void *vsp_dmalloc(vsp_ctx *ctx, size_t bytes);

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "vsp_stats_reset": (None, [_P]),
     "vsp_set_option": (_I, [_P, C.c_char_p, C.c_long]),
     "vsp_diag_clock": (_I, [_P, _I, _P, _P]),
+    "vsp_diag_clock_ntt": (_I, [_P, _I, _P, _P]),
     "vsp_dmalloc": (_P, [_P, _SZ]),
     "vsp_dfree": (None, [_P, _P]),
     "vsp_h2d": (_I, [_P, _P, _P, _SZ]),

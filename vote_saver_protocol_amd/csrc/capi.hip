@@ -224,6 +224,11 @@ int vsp_diag_clock(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out) 
     VSP_HIP(hipSetDevice(ctx->device));
     return msm_diag_clock(ctx, reset, ghz_out, waves_out);
 }
+int vsp_diag_clock_ntt(vsp_ctx *ctx, int reset, double *ghz_out, double *waves_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    VSP_HIP(hipSetDevice(ctx->device));
+    return ntt_diag_clock(ctx, reset, ghz_out, waves_out);
+}
 int vsp_set_option(vsp_ctx *ctx, const char *name, long value) {
     if (!ctx || !name) return VSP_ERR_ARG;
     ctx->opts[name] = value;

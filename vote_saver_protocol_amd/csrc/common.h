@@ -193,6 +193,9 @@ int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
 
 // ---- internal entry points (each implemented in its own .hip) ----
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+bool ntt29_in_use(vsp_ctx *ctx);
+int ntt_device_batch(vsp_ctx *ctx, Fr *const *d_a, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+int ntt_device_fused_abc(vsp_ctx *ctx, const Fr *d_a, const Fr *d_b, const Fr *d_c, Fr *d_h, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
 int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m);
 void ntt_selfcheck_once(vsp_ctx *ctx);                          // known-answer check of the 29-bit butterfly kernel, before any table set-up
 int ntt_ensure_coset_tables(vsp_ctx *ctx, unsigned log_m, const uint64_t *g4);
@@ -234,6 +237,7 @@ int bases_to_mont_g2(vsp_ctx *ctx, const void *d_canon, G2Affine *d_out, size_t 
 // raises bit 2 of *d_flag when some point fails phi(P) = lambda P (the endomorphism split's precondition; msm_impl.inc k_subgroup_check)
 int subgroup_check_g1(vsp_ctx *ctx, const G1Affine *d_mont, size_t n, uint32_t *d_flag);
 int msm_diag_clock(vsp_ctx *ctx, int reset, double *ghz, double *waves);
+int ntt_diag_clock(vsp_ctx *ctx, int reset, double *ghz, double *waves);
 int subgroup_check_g2(vsp_ctx *ctx, const G2Affine *d_mont, size_t n, uint32_t *d_flag);
 // resident bases from canonical points; trust: BASES_CALLER = caller data (validated; the split only after the subgroup check),
 // BASES_OWN = points this library computed as multiples of a generator (in the subgroup by construction: no check),

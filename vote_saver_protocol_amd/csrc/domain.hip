@@ -323,6 +323,20 @@ int domain_lagrange_device(vsp_ctx *ctx, const vsp_domain *d, const HFr &t, Fr *
 int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, const vsp_domain *d, Fr *dH) {
     const size_t m = d->m;
     Fr *v[3] = {dA, dB, dC};
+    { long batched = 1; auto it = ctx->opts.find("witness_map_batched"); if (it != ctx->opts.end()) batched = it->second;
+      if (batched && !d->step && m >= 2 && ntt29_in_use(ctx)) {
+        // basic radix-2 domain, 29-bit butterflies: the three inverse transforms as ONE launch per pass, the three coset transforms likewise, and
+        // the pointwise step A B - C inside the first pass of the last transform: 3 x passes launches instead of 7 x passes + 1, and the
+        // 128 bytes per element the pointwise kernel moved stay in registers.  (Option "witness_map_batched" = 0: the sequence below.)
+        unsigned log_m = 0; while (((size_t)1 << log_m) < m) log_m++;
+        VSP_TRY(ntt_device_batch(ctx, v, 3, log_m, 1, nullptr, nullptr));
+        VSP_TRY(ntt_device_batch(ctx, v, 3, log_m, 0, G7, nullptr));
+        // the fused load leaves (a b - c) 2^-261: 2^261 = 32 R goes into the scale with 1 / Z(g), constant on the coset of a basic domain
+        const uint64_t c32[4] = {32, 0, 0, 0};
+        HFr extra = mul(mul(HFr::r2(), host_load_canon<HFr>(c32)), d->zinv_const);
+        VSP_TRY(ntt_device_fused_abc(ctx, dA, dB, dC, dH, log_m, 1, G7, &extra));
+        return VSP_OK;
+      } }
     for (int k = 0; k < 3; k++) {
         VSP_TRY(domain_fft_device(ctx, d, v[k], 1, nullptr, nullptr));
         VSP_TRY(domain_fft_device(ctx, d, v[k], 0, G7, nullptr));

@@ -165,6 +165,14 @@ struct NttPass29Args {
     int first, last, premul, postmul;
     Planes29 tw, pw_lo, pw_hi;
     Fr29 scale;             // Montgomery (R') form, canonical; the Montgomery one when no scaling is asked for
+    // a BATCH of up to three transforms of one size in one launch (grid.y; r1cs_to_qap::witness_map runs three at every step): transform b
+    // reads the canonical words of in[b] in its first pass, writes those of out[b] in its last, and keeps its lazy values between passes
+    // in the slice [b 2^log_n, (b + 1) 2^log_n) of every scratch plane
+    const Fr *in[3];
+    Fr *out[3];
+    // fused load of the first pass (witness_map's last transform): the value transformed is in[0][i] * fuse_b[i] - fuse_c[i], left with the
+    // factor 2^-261 of the two products (the caller folds 2^261 into the scale); nullptr: plain load
+    const Fr *fuse_b, *fuse_c;
 };
 __device__ __forceinline__ Fr29 ld29(const Planes29 &t, size_t j) {
     Fr29 v; uint4 a = t.p0[j], b = t.p1[j];
@@ -182,11 +190,22 @@ __device__ __forceinline__ void lds_store29(uint4 *pl0, uint4 *pl1, uint32_t *pl
     pl2[e] = v.l[8];
 }
 
-__global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(const Fr *__restrict__ in_words, Planes29 in_lazy, Fr *__restrict__ out_words, PlanesOut29 out_lazy,
-                                                            NttPass29Args p) {
+#ifdef VSP_DIAG_CLOCK
+__device__ unsigned long long vsp_diag_ntt_sums[4];          // shader cycles, 100 MHz ticks, waves (diagnostic build only)
+#endif
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, PlanesOut29 out_lazy, NttPass29Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint4 lds[2u << NTT_TILE_LOG];
     __shared__ uint32_t lds8[1u << NTT_TILE_LOG];
+    const Fr *__restrict__ in_words = p.in[blockIdx.y];
+    Fr *__restrict__ out_words = p.out[blockIdx.y];
+    { const size_t boff = (size_t)blockIdx.y << p.log_n;          // this transform's slice of the scratch planes
+      in_lazy.p0 += boff; in_lazy.p1 += boff; in_lazy.p2 += boff; out_lazy.p0 += boff; out_lazy.p1 += boff; out_lazy.p2 += boff; }
+#ifdef VSP_DIAG_CLOCK
+    // DIAGNOSTIC BUILD ONLY (libvsp_hip_diag.so): the clock the chip holds inside a pass, stamped once per wave around the whole pass
+    unsigned long long dc_t0, dc_r0, dc_t1, dc_r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dc_t0), "=s"(dc_r0) :: "memory");
+#endif
     const unsigned K = p.s1 - p.s0;
     const unsigned C = 1u << p.clog;
     const unsigned tile = 1u << (K + p.clog);
@@ -208,6 +227,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(const Fr *__restrict
         Fr29 v;
         if (p.first) {
             v = fr29_from_words(in_words[src]);
+            if (p.fuse_b) {                                       // (a b - c) / 2^261: two products of canonical operands, one lazy subtraction, one carry pass
+                Fr29 one; for (int k = 0; k < 9; k++) one.l[k] = k == 0 ? 1u : 0u;
+                v = norm29(sub29(mul29(v, fr29_from_words(p.fuse_b[src])), mul29(fr29_from_words(p.fuse_c[src]), one)));
+            }
             if (p.premul) v = mul29(v, mul29(ld29(p.pw_lo, src & ((1u << PW_LOG) - 1u)), ld29(p.pw_hi, src >> PW_LOG)));
         } else v = ld29(in_lazy, src);
         lds_store29(pl0, pl1, pl2, e, v);
@@ -270,6 +293,12 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(const Fr *__restrict
             out_lazy.p2[pos] = v.l[8];
         }
     }
+#ifdef VSP_DIAG_CLOCK
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dc_t1), "=s"(dc_r1) :: "memory");
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&vsp_diag_ntt_sums[0], dc_t1 - dc_t0); atomicAdd(&vsp_diag_ntt_sums[1], dc_r1 - dc_r0); atomicAdd(&vsp_diag_ntt_sums[2], 1ull);
+    }
+#endif
 #endif
 }
 
@@ -290,6 +319,21 @@ __global__ __launch_bounds__(256) void k_fill_twiddles(Fr *T, const Fr *A, const
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+// diagnostic build: clock held inside the passes of the 29-bit transform since the last reset
+int ntt_diag_clock(vsp_ctx *ctx, int reset, double *ghz, double *waves) {
+#ifdef VSP_DIAG_CLOCK
+    unsigned long long h[4] = {0, 0, 0, 0};
+    VSP_HIP(hipStreamSynchronize(ctx->stream));
+    VSP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(vsp_diag_ntt_sums), sizeof h));
+    if (ghz) *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+    if (waves) *waves = (double)h[2];
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; VSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vsp_diag_ntt_sums), z, sizeof z)); }
+    return VSP_OK;
+#else
+    (void)reset; if (ghz) *ghz = 0.0; if (waves) *waves = 0.0;
+    return set_error(ctx, VSP_ERR_UNSUPPORTED, "diag_clock: this is not the diagnostic build (make diag -> libvsp_hip_diag.so)");
+#endif
+}
 static const uint64_t FR_ROOT_2_32[4] = {0x3829971f439f0d2bULL, 0xb63683508c2280b9ULL, 0xd09b681922c813b4ULL, 0x16a2a19edfe81f20ULL};
 
 HFr host_omega(unsigned log_m) {
@@ -454,9 +498,36 @@ void ntt_selfcheck_once(vsp_ctx *ctx) {
     if (want29 && ctx->ntt29_checked == 0) ntt29_known_answer_check(ctx);
 }
 
+// whether the 29-bit butterflies are in use on this context (runs their known-answer check when it has not run yet)
+bool ntt29_in_use(vsp_ctx *ctx) {
+    long want29 = 1; { auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) want29 = it->second; }
+    if (!want29) return false;
+    if (ctx->ntt29_checked <= 0 && !ntt29_known_answer_check(ctx)) return false;
+    { auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) want29 = it->second; }
+    return want29 != 0;
+}
+static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g,
+                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c);
 // d_a: n canonical Fr values in device memory, transformed in place.
 // extra_scale (optional, host Montgomery): an additional constant multiplied into every output.
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    const Fr *in[1] = {d_a}; Fr *out[1] = {d_a};
+    return ntt_device_impl(ctx, in, out, 1, log_m, inverse, coset_g, extra_scale, nullptr, nullptr);
+}
+// `count` (<= 3) transforms of one size in ONE launch per pass, in place (29-bit butterflies only: callers ask ntt29_in_use first)
+int ntt_device_batch(vsp_ctx *ctx, Fr *const *d_a, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    if (count < 1 || count > 3) return set_error(ctx, VSP_ERR_ARG, "ntt: batch of 1..3 transforms");
+    const Fr *in[3] = {d_a[0], count > 1 ? d_a[1] : nullptr, count > 2 ? d_a[2] : nullptr};
+    return ntt_device_impl(ctx, in, d_a, count, log_m, inverse, coset_g, extra_scale, nullptr, nullptr);
+}
+// d_h = transform of (a[i] b[i] - c[i]) 2^-261, the pointwise step fused into the first pass's load (29-bit butterflies only)
+int ntt_device_fused_abc(vsp_ctx *ctx, const Fr *d_a, const Fr *d_b, const Fr *d_c, Fr *d_h, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    const Fr *in[1] = {d_a}; Fr *out[1] = {d_h};
+    return ntt_device_impl(ctx, in, out, 1, log_m, inverse, coset_g, extra_scale, d_b, d_c);
+}
+static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g,
+                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c) {
+    Fr *d_a = d_out[0];
     if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: log_m > 28");
     if (coset_g) {
         uint64_t z = coset_g[0] | coset_g[1] | coset_g[2] | coset_g[3];
@@ -482,8 +553,9 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
 
     long use29 = 1; { auto it = ctx->opts.find("ntt_fr29"); if (it != ctx->opts.end()) use29 = it->second; }
     if (use29 && !check29_ok) use29 = 0;
+    if (!use29 && (count > 1 || fuse_b || d_in[0] != d_out[0])) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: batched / fused transforms need the 29-bit butterflies");
     Fr *scratch = nullptr;
-    if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, n * (use29 ? 36 : sizeof(Fr)))); scratch = (Fr *)ctx->ntt_scratch.p; }
+    if (npass > 1) { VSP_TRY(ensure(ctx, ctx->ntt_scratch, (size_t)count * n * (use29 ? 36 : sizeof(Fr)))); scratch = (Fr *)ctx->ntt_scratch.p; }
 
     HFr scale = HFr::one();
     bool have_scale = false;
@@ -495,7 +567,7 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
         VSP_TRY(ntt29_ensure_tables(ctx, coset_g != nullptr));
         const size_t tcount = (size_t)1 << (ctx->ntt.log - 1);
         const size_t L = (size_t)1 << PW_LOG, pn = (size_t)1 << ctx->ntt.pw_log, H = pn > L ? (pn >> PW_LOG) : 1;
-        Planes29 lazy_in = planes_of(ctx->ntt_scratch, n);
+        Planes29 lazy_in = planes_of(ctx->ntt_scratch, (size_t)count * n);
         PlanesOut29 lazy_out; lazy_out.p0 = (uint4 *)lazy_in.p0; lazy_out.p1 = (uint4 *)lazy_in.p1; lazy_out.p2 = (uint32_t *)lazy_in.p2;
         unsigned s0 = 0;
         for (unsigned i = 0; i < npass; i++) {
@@ -511,9 +583,11 @@ int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_
             if (p.premul) { p.pw_lo = planes_of(ctx->ntt.pw29[0], L); p.pw_hi = planes_of(ctx->ntt.pw29[1], H); }
             if (p.postmul == 2) { p.pw_lo = planes_of(ctx->ntt.pw29[2], L); p.pw_hi = planes_of(ctx->ntt.pw29[3], H); }
             p.scale = host_to_fr29_mont(scale);
+            for (unsigned b = 0; b < count; b++) { p.in[b] = d_in[b]; p.out[b] = d_out[b]; }
+            if (p.first) { p.fuse_b = fuse_b; p.fuse_c = fuse_c; }
             if (!p.first && p.s0 < p.clog) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: pass plan");
             const unsigned tile_log = stages[i] + p.clog;
-            hipLaunchKernelGGL(k_ntt29_pass, dim3((unsigned)(n >> tile_log)), dim3(NTT_THREADS), 0, ctx->stream, (const Fr *)d_a, lazy_in, d_a, lazy_out, p);
+            hipLaunchKernelGGL(k_ntt29_pass, dim3((unsigned)(n >> tile_log), count), dim3(NTT_THREADS), 0, ctx->stream, lazy_in, lazy_out, p);
             VSP_LAUNCH_CHECK();
             s0 = p.s1;
         }
