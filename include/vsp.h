@@ -153,6 +153,13 @@ int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t 
                      const void *d_scalars, uint64_t *out_affine, int *out_is_inf);
 /* Same, but the result is left as a Jacobian partial sum (X, Y, Z canonical: 18 / 36 uint64) in the host
  * buffer -- the fixed-size record ranks exchange in the sharded multi-GPU MSM. */
+/* A BATCH of multi-exponentiations over the same resident bases: `batch` (1..64) scalar vectors of n canonical scalars each, vector k at
+ * d_scalars + 32 * k * stride bytes (stride >= n, in scalars), out_affine[k] / out_is_inf[k] = sum_i scalars_k[i] * bases[first + i].
+ * One digit sort, one bucket accumulation and one bucket reduction serve all vectors (separate buckets per vector, the same base rows):
+ * what a prover of MANY small statements over one key needs -- small multi-exponentiations are bound by the latency of their dependent
+ * chains, not by work, and a batch is as wide as its vectors together at the latency of one.  Plain bases only (no window multiples). */
+int vsp_msm_resident_batch(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, size_t batch, size_t stride,
+                           uint64_t *out_affine /* batch x 12 or 24 */, int *out_is_inf /* batch, may be NULL */);
 int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n,
                               const void *d_scalars, uint64_t *out_jacobian);
 /* Pipelined form: vsp_msm_launch enqueues the whole multi-exponentiation on work slot `slot` (0..5; slot 0 runs on the
@@ -253,6 +260,14 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
                       const uint64_t *saver_P1 /* 12 or NULL */, const uint64_t *saver_r_enc /* 4 or NULL */,
                       uint64_t A_out[12], uint64_t B_out[24], uint64_t C_out[12], uint8_t proof_out[192]);
 
+/* A BATCH of proofs over one key: `count` (1..64) witnesses of num_vars canonical values each, one after the other; r, s: count x 4 words;
+ * outputs count x 12 / 24 / 12 words and count x 192 bytes (any may be NULL).  Proof k is byte-identical to vsp_groth16_prove(witness_k,
+ * r_k, s_k).  Proofs of a small circuit (2^15..2^16 constraints) are bound by the latency of their dependent kernel chains, not by work:
+ * proved together, the same launches run `count` times as wide -- one witness_map over 3 x count transforms, every multi-exponentiation
+ * once over `count` scalar vectors.  Needs a PLAIN key (vsp_groth16_generate with precompute = 0: 10 x less memory than the tables of
+ * window multiples, which buy a single proof ~5 %); VSP_ERR_UNSUPPORTED otherwise.  No SAVER addend (vsp_saver_encrypt proves one vote). */
+int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count,
+                            const uint64_t *r, const uint64_t *s, uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out);
 /* The same proof in two halves, so that ONE host thread keeps several proofs in flight over one resident key -- one per context:
  *     vsp_groth16_prove_launch(ctxA, ...); vsp_groth16_prove_launch(ctxB, ...); vsp_groth16_prove_finish(ctxA, ...); launch(ctxA, next) ...
  * launch queues every kernel of the proof on the context's streams and returns (it copies r, s and the SAVER term; a witness in

@@ -654,3 +654,45 @@ def test_msm_same_result_under_every_kernel_variant_option(cref, option, value):
 
 
 _VARIANT_CASES = {}
+
+
+@pytest.mark.parametrize("group,n,K,kinds", [(1, 1, 3, "uniform"), (1, 300, 4, "mixed"), (1, 3000, 5, "mixed"), (1, 40000, 8, "mixed"), (1, 70000, 3, "boolean"),
+                                             (2, 257, 3, "mixed"), (2, 2500, 4, "mixed"), (1, 2000, 16, "boolean")])
+def test_batch_of_scalar_vectors_over_one_set_of_bases(ctx, cref, group, n, K, kinds):
+    """vsp_msm_resident_batch (round 4): K scalar vectors over the same resident bases in ONE pass -- one sort, one accumulation, one bucket
+    reduction over K x windows bucket sets -- must give, vector by vector, what K separate multi-exponentiations give (the C oracle's
+    multiexp_with_mixed_addition): uniform, 90 % boolean, all-equal, all-zero and edge-valued vectors mixed in one batch, a stride
+    larger than n, with and without the endomorphism split, a sub-range of the bases"""
+    bases = (cref.g1_batch_mul_gen if group == 1 else cref.g2_batch_mul_gen)(rand_fr_array(n + 5, 500 + n))
+    msm = cref.msm_g1 if group == 1 else cref.msm_g2
+    stride = n + 7
+    rng = np.random.default_rng(n + K)
+    vecs = np.zeros((K, stride, 4), np.uint64)
+    for k in range(K):
+        ss = rand_fr_array(n, 600 + 10 * n + k)
+        kind = kinds if kinds != "mixed" else ("uniform", "boolean", "equal", "zero", "edges")[k % 5]
+        if kind == "boolean":
+            m = rng.random(n) < 0.9; ss[m] = 0; ss[m, 0] = rng.integers(0, 2, size=int(m.sum()), dtype=np.uint64)
+        elif kind == "equal":
+            ss[:] = ss[0]
+        elif kind == "zero":
+            ss[:] = 0
+        elif kind == "edges":
+            for i in range(0, n, 3): ss[i] = L(o.R - 1 - (i % 3), 4)
+            for i in range(1, n, 5): ss[i] = 0
+        vecs[k, :n] = ss
+        vecs[k, n:] = rand_fr_array(stride - n, 7)            # what lies between two vectors must not matter
+    d_s = ctx.to_device(vecs.reshape(-1, 4))
+    for glv in (1, 0):
+        ctx.set_option("msm_glv", glv)
+        B = ctx.upload_bases(bases, group)
+        for first in (0, 3):
+            cnt = n if first == 0 else n - 1
+            got, inf = B.msm_batch(d_s, K, n=cnt, first=first, stride=stride)
+            for k in range(K):
+                exp = msm(bases[first:first + cnt], vecs[k, :cnt], mixed=True)
+                assert np.array_equal(got[k], exp), (group, n, K, glv, first, k)
+                assert bool(inf[k]) == (not exp.any())
+        B.free()
+    ctx.set_option("msm_glv", 1)
+    ctx.dfree(d_s)

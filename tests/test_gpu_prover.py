@@ -236,3 +236,60 @@ def test_prove_in_two_halves_and_from_a_packed_witness(cref):
             v.groth16_prove_finish(c1)
         assert v.groth16_prove(c1, dcs, pk, wit, r, s)[3] == ref[3]
         pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+@pytest.mark.parametrize("nc,ni,K", [(10, 2, 3), (300, 5, 4), (2000, 30, 8), (5000, 3, 2)])
+def test_batch_of_proofs_is_byte_identical_to_single_proofs_and_the_oracle(ctx, cref, nc, ni, K):
+    """vsp_groth16_prove_batch (round 4): K witnesses of one constraint system proved in one pass over a plain key -- every proof equals the
+    oracle's r1cs_gg_ppzksnark proof and vsp_groth16_prove's 192 bytes for the same (witness, r, s), under K different (r, s); a key with
+    tables of window multiples is refused."""
+    cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=nc + K)
+    gen = o.splitmix64(7 * nc + K)
+    wits, rs, ss = [wit0], [r0], [s0]
+    for k in range(1, K):
+        w = wit0.copy()                                         # the same witness under other randomness (different witnesses: the next test)
+        wits.append(w); rs.append(L(o.rand_fr(gen), 4)); ss.append(L(o.rand_fr(gen), 4))
+    W = np.stack(wits); R = np.stack(rs); S = np.stack(ss)
+    A, B, Cc, proofs = v.groth16_prove_batch(ctx, dcs, pk, W, R, S)
+    for k in range(K):
+        eA, eB, eC = kp.prove(wits[k], rs[k], ss[k])
+        assert np.array_equal(A[k], eA) and np.array_equal(B[k], eB) and np.array_equal(Cc[k], eC), k
+        sA, sB, sC, sproof = v.groth16_prove(ctx, dcs, pk, wits[k], rs[k], ss[k])
+        assert proofs[k] == sproof and np.array_equal(A[k], sA), k
+    # a key with tables of window multiples is refused, the context stays usable
+    q[0].precompute(12)
+    with pytest.raises(v.VspError):
+        v.groth16_prove_batch(ctx, dcs, pk, W, R, S)
+    assert v.groth16_prove(ctx, dcs, pk, wits[0], rs[0], ss[0])[3] == proofs[0]
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_batch_of_proofs_over_different_witnesses(ctx, cref):
+    """the witnesses of a batch are independent vectors: K different satisfying assignments of one system (the synthetic system's boolean
+    wires that no product wire reads may take either value), each proof against the oracle"""
+    nc, ni, K = 1200, 6, 5
+    cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=77)
+    A_, B_, C_ = cs.export()
+    read_by_product = set()
+    for j in range(nc):
+        a, b, c = int(A_[1][j]), int(B_[1][j]), int(C_[1][j])
+        if not (a == b == c):
+            read_by_product.add(a); read_by_product.add(b)
+    free_bool = [int(C_[1][j]) for j in range(nc) if int(A_[1][j]) == int(B_[1][j]) == int(C_[1][j]) and int(C_[1][j]) not in read_by_product]
+    assert len(free_bool) > 100
+    rng = np.random.default_rng(3)
+    gen = o.splitmix64(99)
+    wits, rs, ss = [], [], []
+    for k in range(K):
+        w = wit0.copy()
+        for idx in free_bool:
+            if rng.random() < 0.5:
+                w[idx - 1] = 0; w[idx - 1, 0] = int(rng.integers(0, 2))
+        assert cs.is_satisfied(w)
+        wits.append(w); rs.append(L(o.rand_fr(gen), 4)); ss.append(L(o.rand_fr(gen), 4))
+    A, B, Cc, proofs = v.groth16_prove_batch(ctx, dcs, pk, np.stack(wits), np.stack(rs), np.stack(ss))
+    assert len({p for p in proofs}) == K
+    for k in range(K):
+        eA, eB, eC = kp.prove(wits[k], rs[k], ss[k])
+        assert np.array_equal(A[k], eA) and np.array_equal(B[k], eB) and np.array_equal(Cc[k], eC), k
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

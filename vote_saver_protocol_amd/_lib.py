@@ -46,6 +46,7 @@ PROTOTYPES = {
     "vsp_keypair_device_bytes": (_SZ, [_P]),
     "vsp_bases_free": (None, [_P, _P]),
     "vsp_msm_resident": (_I, [_P, _P, _SZ, _SZ, _P, _P, _P]),
+    "vsp_msm_resident_batch": (_I, [_P, _P, _SZ, _SZ, _P, _SZ, _SZ, _P, _P]),
     "vsp_msm_resident_jacobian": (_I, [_P, _P, _SZ, _SZ, _P, _P]),
     "vsp_msm_launch": (_I, [_P, _U, _P, _SZ, _SZ, _P]),
     "vsp_msm_finish_jacobian": (_I, [_P, _U, _P]),
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "vsp_pk_create": (_P, [_P] * 11),
     "vsp_pk_free": (None, [_P, _P]),
     "vsp_groth16_prove": (_I, [_P] * 12),
+    "vsp_groth16_prove_batch": (_I, [_P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "vsp_groth16_prove_launch": (_I, [_P] * 8),
     "vsp_groth16_prove_finish": (_I, [_P] * 5),
     "vsp_witness_pack_words": (_SZ, [_SZ]),

@@ -164,6 +164,16 @@ class Bases:
         self.ctx.check(self.ctx.lib.vsp_msm_resident(self.ctx.h, self.h, first, n, _ptr(d_scalars), _ptr(out), C.byref(inf)))
         return out, bool(inf.value)
 
+    def msm_batch(self, d_scalars, batch, n=None, first=0, stride=None):
+        """`batch` multi-exponentiations over the same bases in one pass (vsp_msm_resident_batch): vector k at d_scalars + 32 * k * stride
+        bytes.  -> (affine [batch, 12 | 24], is_inf [batch])."""
+        n = self.n - first if n is None else n
+        stride = n if stride is None else stride
+        out = np.zeros((batch, 12 if self.group == 1 else 24), np.uint64)
+        inf = np.zeros(batch, np.int32)
+        self.ctx.check(self.ctx.lib.vsp_msm_resident_batch(self.ctx.h, self.h, first, n, _ptr(d_scalars), batch, stride, _ptr(out), _ptr(inf)))
+        return out, inf.astype(bool)
+
     def msm_launch(self, slot, d_scalars, n=None, first=0):
         """Enqueue the multi-exponentiation on work slot `slot` (own stream); pair with msm_finish_jacobian(slot)."""
         n = self.n - first if n is None else n
@@ -461,6 +471,20 @@ def groth16_prove(ctx, cs, pk, witness, r, s, saver_P1=None, saver_r_enc=None):
     ctx.check(ctx.lib.vsp_groth16_prove(ctx.h, cs.h, pk.h, _ptr(witness), _ptr(_u64(r)), _ptr(_u64(s)), _ptr(p1), _ptr(re),
                                         _ptr(A), _ptr(B), _ptr(Cc), _ptr(proof)))
     return A, B, Cc, proof.tobytes()
+
+
+def groth16_prove_batch(ctx, cs, pk, witnesses, r, s):
+    """K proofs over one PLAIN key in one pass (vsp_groth16_prove_batch): witnesses [K, num_vars, 4], r / s [K, 4].
+    -> (A [K, 12], B [K, 24], C [K, 12], [proof bytes] * K); proof k is byte-identical to groth16_prove(witness_k, r_k, s_k)."""
+    witnesses = np.ascontiguousarray(witnesses, dtype=np.uint64)
+    if witnesses.ndim != 3 or witnesses.shape[1:] != (cs.num_vars, 4):
+        raise ValueError("prove_batch: witnesses must be [K, num_vars, 4]")
+    K = witnesses.shape[0]
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(K, 4); s = np.ascontiguousarray(s, dtype=np.uint64).reshape(K, 4)
+    A = np.zeros((K, 12), np.uint64); B = np.zeros((K, 24), np.uint64); Cc = np.zeros((K, 12), np.uint64)
+    proofs = np.zeros((K, 192), np.uint8)
+    ctx.check(ctx.lib.vsp_groth16_prove_batch(ctx.h, cs.h, pk.h, _ptr(witnesses), K, _ptr(r), _ptr(s), _ptr(A), _ptr(B), _ptr(Cc), _ptr(proofs)))
+    return A, B, Cc, [proofs[k].tobytes() for k in range(K)]
 
 
 class PackedWitness:

@@ -501,6 +501,16 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
     return msm_g2_launch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, plan_from_slot, nullptr,
                          bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28x2) * (bases->glv ? 2 : 1) : nullptr, bases->glv);
 }
+// the same for a batch of scalar vectors (vector k at d_scalars + k * stride) over PLAIN resident bases: one launch, one result per vector
+int launch_on_bases_batch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, unsigned batch, size_t stride, bool dense) {
+    if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
+    if (bases->pre_c) return set_error(ctx, VSP_ERR_UNSUPPORTED, "msm: a batch runs over plain bases (no table of window multiples)");
+    if (bases->group == 1)
+        return msm_g1_launch_batch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, batch, stride, dense,
+                                   bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28) * (bases->glv ? 2 : 1) : nullptr, bases->glv);
+    return msm_g2_launch_batch(ctx, slot, (const G2Affine *)bases->d + first, d_scalars, n, batch, stride, dense,
+                               bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28x2) * (bases->glv ? 2 : 1) : nullptr, bases->glv);
+}
 }  // namespace vsp
 extern "C" {
 
@@ -567,6 +577,26 @@ int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t 
     XYZZ<HFp> a1; XYZZ<HFp2> a2;
     VSP_TRY(msm_resident_xyzz(ctx, bases, first, n, d_scalars, &a1, &a2));
     return bases->group == 1 ? finish_affine<Fp, HFp>(a1, out_affine, out_is_inf) : finish_affine<Fp2, HFp2>(a2, out_affine, out_is_inf);
+}
+
+int vsp_msm_resident_batch(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, size_t batch, size_t stride,
+                           uint64_t *out_affine, int *out_is_inf) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!bases || (!d_scalars && n) || !out_affine || batch < 1 || batch > 64 || (batch > 1 && stride < n)) return set_error(ctx, VSP_ERR_ARG, "msm: bad batch argument");
+    if (first > bases->n || n > bases->n - first) return set_error(ctx, VSP_ERR_ARG, "msm: range outside the resident bases");
+    VSP_HIP(hipSetDevice(ctx->device));
+    const size_t words = bases->group == 1 ? 12 : 24;
+    VSP_TRY(launch_on_bases_batch(ctx, 0, bases, first, n, (const Fr *)d_scalars, (unsigned)batch, stride, false));
+    if (bases->group == 1) {
+        std::vector<XYZZ<HFp>> r(batch);
+        VSP_TRY(msm_g1_finish_batch(ctx, 0, r.data(), (unsigned)batch));
+        for (size_t k = 0; k < batch; k++) VSP_TRY((finish_affine<Fp, HFp>(r[k], out_affine + k * words, out_is_inf ? out_is_inf + k : nullptr)));
+    } else {
+        std::vector<XYZZ<HFp2>> r(batch);
+        VSP_TRY(msm_g2_finish_batch(ctx, 0, r.data(), (unsigned)batch));
+        for (size_t k = 0; k < batch; k++) VSP_TRY((finish_affine<Fp2, HFp2>(r[k], out_affine + k * words, out_is_inf ? out_is_inf + k : nullptr)));
+    }
+    return VSP_OK;
 }
 
 int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, uint64_t *out_jacobian) {

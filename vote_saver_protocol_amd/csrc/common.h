@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "../../include/vsp.h"
+#include <thread>
+#include <vector>
 #include "curve.h"
 
 namespace vsp {
@@ -50,6 +52,11 @@ struct MsmGeom {
     unsigned lb;        // windows wider than 16 bits: the low bits of the bucket index that the second sort pass orders (c - 16); 0 otherwise
     unsigned fold;      // 255-bit scalars are read as min(k, r - k) < 2^254 with the sign flipped: one window fewer where c divides 255 (c = 15, 17)
     unsigned bd;        // slots per digit in the k_dimbits result layout: 8 (digits of up to 8 bits, three of them) or 12 (two digits of up to 12 bits)
+    // a BATCH of K scalar vectors over one set of bases (round 4: vsp_groth16_prove_batch): vector k starts kstride elements after vector
+    // k - 1, its Wk windows are the windows k Wk .. (k + 1) Wk - 1 of the W = K Wk the rest of the pipeline sees -- separate bucket sets per
+    // (vector, window), the same base rows: the sort, the accumulation and the bucket reduction run ONCE, K times as wide.  K = 1: Wk = W.
+    unsigned K, Wk;
+    size_t kstride;
 };
 // reference to the precomputed window multiples of resident bases
 struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; bool glv; };   // table28: the same table on 14 x 28-bit limbs (fp28.h), or null;
@@ -57,7 +64,7 @@ struct MsmPre { size_t stride; size_t first; unsigned c; const void *table28; bo
 
 // one in-flight MSM: its stream, device workspaces (grow only) and the pinned landing buffer of its window results
 struct MsmWork {
-    static constexpr size_t PINNED_BYTES = 256 * 1024;
+    static constexpr size_t PINNED_BYTES = 256 * 1024;       // window results land here (25 records of 192 / 384 bytes per window at most); a batch grows it (pinned_cap)
     bool inited = false, own_stream = false, active = false, empty = false;
     bool dimbits = false;                  // layout of the window results of the last launch (msm_impl.inc k_dimbits / k_dimweight)
     hipStream_t stream = nullptr;          // the stream launches queue on: the slot's own one, or a borrowed one (msm_slot_use_stream)
@@ -71,6 +78,7 @@ struct MsmWork {
     DevBuf glv_scalars;                  // endomorphism split: 2n half-length scalars k1_i, k2_i (interleaved)
     bool glv = false;                    // this launch runs over the split scalars and the interleaved (P, phi(P)) table
     void *h_pinned = nullptr;
+    size_t pinned_cap = 0;
     // vsp_msm_finish_jacobian_device: the Jacobian record leaves through a small pinned ring (REC_RING entries of 288 bytes) so that the
     // copy into the caller's device buffer is an asynchronous DMA; rec_ev[k] marks the copy out of entry k as done
     static constexpr unsigned REC_RING = 4;
@@ -117,6 +125,7 @@ struct vsp_ctx {
     vsp::DevBuf fb_g1, fb_g2, fb_tmp, fb_pre;
     // prover workspaces
     vsp::DevBuf pr_z, pr_a, pr_b, pr_c, pr_h, pr_pack;
+    vsp::DevBuf pr_bz, pr_babc, pr_bh;      // vsp_groth16_prove_batch: [K][num_vars + 1], [K][3][m], [K][m]
     // a proof in flight between vsp_groth16_prove_launch and _finish (one per context)
     struct { bool active = false; const vsp_pk *pk = nullptr; uint64_t r[4], s[4], P1[12], r_enc[4]; bool has_saver = false; } prove;
 };
@@ -176,6 +185,18 @@ struct vsp_pk {
 namespace vsp {
 
 int set_hip_error(vsp_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
+// f(0) .. f(n - 1) on up to `max_threads` host threads (the host steps of a BATCH: the Horner chains over the window results of K
+// multi-exponentiations and the assembly of K proofs are independent pieces of a few hundred group operations each)
+template <class Fn> inline void host_parallel_for(size_t n, Fn f, unsigned max_threads = 16) {
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    size_t T = n < hw ? n : hw; if (T > max_threads) T = max_threads;
+    if (T <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (size_t t = 1; t < T; t++) th.emplace_back([=]() { for (size_t i = t; i < n; i += T) f(i); });
+    for (size_t i = 0; i < n; i += T) f(i);
+    for (auto &x : th) x.join();
+}
 int set_error(vsp_ctx *ctx, int code, const char *msg);
 int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
 
@@ -194,6 +215,10 @@ int ensure(vsp_ctx *ctx, DevBuf &b, size_t bytes);
 // ---- internal entry points (each implemented in its own .hip) ----
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
 bool ntt29_in_use(vsp_ctx *ctx);
+int ntt_device_strided(vsp_ctx *ctx, Fr *base, unsigned count, size_t stride, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+int ntt_device_fused_abc_strided(vsp_ctx *ctx, const Fr *d_a, size_t off_b, size_t off_c, size_t in_stride, Fr *d_h, size_t out_stride, unsigned count, unsigned log_m,
+                                 int inverse, const uint64_t *coset_g, const HFr *extra_scale);
+int witness_map_device_batch(vsp_ctx *ctx, Fr *abc, unsigned count, const vsp_domain *d, Fr *dH);
 int ntt_device_batch(vsp_ctx *ctx, Fr *const *d_a, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
 int ntt_device_fused_abc(vsp_ctx *ctx, const Fr *d_a, const Fr *d_b, const Fr *d_c, Fr *d_h, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale);
 int ntt_ensure_twiddles(vsp_ctx *ctx, unsigned log_m);
@@ -224,7 +249,13 @@ int msm_g1_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
 int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, int plan_from_slot, const MsmPre *pre,
                   const void *plain_table28 = nullptr, bool glv = false);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
+// a batch of scalar vectors over one set of PLAIN bases (MsmGeom.K): vector k at d_scalars + k * stride; one result per vector
+int msm_g1_launch_batch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv);
+int msm_g1_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out, unsigned batch);
+int msm_g2_launch_batch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv);
+int msm_g2_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out, unsigned batch);
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot);
+int launch_on_bases_batch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, unsigned batch, size_t stride, bool dense);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
 int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);

@@ -355,4 +355,21 @@ int witness_map_device(vsp_ctx *ctx, Fr *dA, Fr *dB, Fr *dC, const vsp_domain *d
     return VSP_OK;
 }
 
+// the same for `count` witnesses: abc holds [count][3][m] evaluation vectors (A z, B z, C z of witness k at abc + 3 k m), dH [count][m].
+// Basic domains on the 29-bit butterflies run 3 count transforms per launch; anything else takes the single form, witness by witness.
+int witness_map_device_batch(vsp_ctx *ctx, Fr *abc, unsigned count, const vsp_domain *d, Fr *dH) {
+    const size_t m = d->m;
+    if (d->step || m < 2 || !ntt29_in_use(ctx)) {
+        for (unsigned k = 0; k < count; k++) VSP_TRY(witness_map_device(ctx, abc + (size_t)3 * k * m, abc + (size_t)(3 * k + 1) * m, abc + (size_t)(3 * k + 2) * m, d, dH + (size_t)k * m));
+        return VSP_OK;
+    }
+    unsigned log_m = 0; while (((size_t)1 << log_m) < m) log_m++;
+    VSP_TRY(ntt_device_strided(ctx, abc, 3 * count, m, log_m, 1, nullptr, nullptr));
+    VSP_TRY(ntt_device_strided(ctx, abc, 3 * count, m, log_m, 0, G7, nullptr));
+    const uint64_t c32[4] = {32, 0, 0, 0};
+    HFr extra = mul(mul(HFr::r2(), host_load_canon<HFr>(c32)), d->zinv_const);
+    VSP_TRY(ntt_device_fused_abc_strided(ctx, abc, m, 2 * m, 3 * m, dH, m, count, log_m, 1, G7, &extra));
+    return VSP_OK;
+}
+
 }  // namespace vsp

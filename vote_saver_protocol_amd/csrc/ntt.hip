@@ -170,6 +170,7 @@ struct NttPass29Args {
     // in the slice [b 2^log_n, (b + 1) 2^log_n) of every scratch plane
     const Fr *in[3];
     Fr *out[3];
+    size_t in_stride, out_stride;      // != 0: transform b reads in[0] + b in_stride and writes out[0] + b out_stride (any number of transforms: a batch of proofs)
     // fused load of the first pass (witness_map's last transform): the value transformed is in[0][i] * fuse_b[i] - fuse_c[i], left with the
     // factor 2^-261 of the two products (the caller folds 2^261 into the scale); nullptr: plain load
     const Fr *fuse_b, *fuse_c;
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, Pl
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint4 lds[2u << NTT_TILE_LOG];
     __shared__ uint32_t lds8[1u << NTT_TILE_LOG];
-    const Fr *__restrict__ in_words = p.in[blockIdx.y];
-    Fr *__restrict__ out_words = p.out[blockIdx.y];
+    const Fr *__restrict__ in_words = p.in_stride ? p.in[0] + (size_t)blockIdx.y * p.in_stride : p.in[blockIdx.y];
+    Fr *__restrict__ out_words = p.out_stride ? p.out[0] + (size_t)blockIdx.y * p.out_stride : p.out[blockIdx.y];
+    const size_t fuse_off = (size_t)blockIdx.y * p.in_stride;      // the fused load's other two operands follow their transform
     { const size_t boff = (size_t)blockIdx.y << p.log_n;          // this transform's slice of the scratch planes
       in_lazy.p0 += boff; in_lazy.p1 += boff; in_lazy.p2 += boff; out_lazy.p0 += boff; out_lazy.p1 += boff; out_lazy.p2 += boff; }
 #ifdef VSP_DIAG_CLOCK
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, Pl
             v = fr29_from_words(in_words[src]);
             if (p.fuse_b) {                                       // (a b - c) / 2^261: two products of canonical operands, one lazy subtraction, one carry pass
                 Fr29 one; for (int k = 0; k < 9; k++) one.l[k] = k == 0 ? 1u : 0u;
-                v = norm29(sub29(mul29(v, fr29_from_words(p.fuse_b[src])), mul29(fr29_from_words(p.fuse_c[src]), one)));
+                v = norm29(sub29(mul29(v, fr29_from_words(p.fuse_b[fuse_off + src])), mul29(fr29_from_words(p.fuse_c[fuse_off + src]), one)));
             }
             if (p.premul) v = mul29(v, mul29(ld29(p.pw_lo, src & ((1u << PW_LOG) - 1u)), ld29(p.pw_hi, src >> PW_LOG)));
         } else v = ld29(in_lazy, src);
@@ -507,7 +509,7 @@ bool ntt29_in_use(vsp_ctx *ctx) {
     return want29 != 0;
 }
 static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g,
-                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c);
+                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c, size_t in_stride = 0, size_t out_stride = 0);
 // d_a: n canonical Fr values in device memory, transformed in place.
 // extra_scale (optional, host Montgomery): an additional constant multiplied into every output.
 int ntt_device(vsp_ctx *ctx, Fr *d_a, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
@@ -525,8 +527,21 @@ int ntt_device_fused_abc(vsp_ctx *ctx, const Fr *d_a, const Fr *d_b, const Fr *d
     const Fr *in[1] = {d_a}; Fr *out[1] = {d_h};
     return ntt_device_impl(ctx, in, out, 1, log_m, inverse, coset_g, extra_scale, d_b, d_c);
 }
+// `count` transforms at base + b * stride, in place, one launch per pass (a batch of proofs: 3 K transforms; 29-bit butterflies only)
+int ntt_device_strided(vsp_ctx *ctx, Fr *base, unsigned count, size_t stride, unsigned log_m, int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    if (count < 1 || count > 65535) return set_error(ctx, VSP_ERR_ARG, "ntt: batch size");
+    const Fr *in[1] = {base}; Fr *out[1] = {base};
+    return ntt_device_impl(ctx, in, out, count, log_m, inverse, coset_g, extra_scale, nullptr, nullptr, stride, stride);
+}
+// d_h + b out_stride = transform of (a b - c) 2^-261 with a = d_a + b in_stride, b = a + off_b, c = a + off_c
+int ntt_device_fused_abc_strided(vsp_ctx *ctx, const Fr *d_a, size_t off_b, size_t off_c, size_t in_stride, Fr *d_h, size_t out_stride, unsigned count, unsigned log_m,
+                                 int inverse, const uint64_t *coset_g, const HFr *extra_scale) {
+    if (count < 1 || count > 65535) return set_error(ctx, VSP_ERR_ARG, "ntt: batch size");
+    const Fr *in[1] = {d_a}; Fr *out[1] = {d_h};
+    return ntt_device_impl(ctx, in, out, count, log_m, inverse, coset_g, extra_scale, d_a + off_b, d_a + off_c, in_stride, out_stride);
+}
 static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out, unsigned count, unsigned log_m, int inverse, const uint64_t *coset_g,
-                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c) {
+                           const HFr *extra_scale, const Fr *fuse_b, const Fr *fuse_c, size_t in_stride, size_t out_stride) {
     Fr *d_a = d_out[0];
     if (log_m > 28) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: log_m > 28");
     if (coset_g) {
@@ -583,7 +598,8 @@ static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out
             if (p.premul) { p.pw_lo = planes_of(ctx->ntt.pw29[0], L); p.pw_hi = planes_of(ctx->ntt.pw29[1], H); }
             if (p.postmul == 2) { p.pw_lo = planes_of(ctx->ntt.pw29[2], L); p.pw_hi = planes_of(ctx->ntt.pw29[3], H); }
             p.scale = host_to_fr29_mont(scale);
-            for (unsigned b = 0; b < count; b++) { p.in[b] = d_in[b]; p.out[b] = d_out[b]; }
+            if (in_stride || out_stride) { p.in[0] = d_in[0]; p.out[0] = d_out[0]; p.in_stride = in_stride; p.out_stride = out_stride; }
+            else for (unsigned b = 0; b < count; b++) { p.in[b] = d_in[b]; p.out[b] = d_out[b]; }
             if (p.first) { p.fuse_b = fuse_b; p.fuse_c = fuse_c; }
             if (!p.first && p.s0 < p.clog) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: pass plan");
             const unsigned tile_log = stages[i] + p.clog;

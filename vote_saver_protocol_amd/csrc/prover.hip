@@ -16,7 +16,9 @@
 namespace vsp {
 
 // ---- sparse mat-vec: out[row] = sum_e coef[e] * z[col[e]],  z canonical, coef Montgomery -> canonical out
-__global__ __launch_bounds__(256) void k_csr_matvec(const uint32_t *rp, const uint32_t *ci, const Fr *co, const Fr *z, size_t rows, Fr *out) {
+__global__ __launch_bounds__(256) void k_csr_matvec(const uint32_t *rp, const uint32_t *ci, const Fr *co, const Fr *z, size_t rows, Fr *out,
+                                                    size_t z_stride = 0, size_t out_stride = 0) {
+    z += (size_t)blockIdx.y * z_stride; out += (size_t)blockIdx.y * out_stride;      // grid.y: the witnesses of a batch
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     Fr acc = Fr::zero();
@@ -419,6 +421,109 @@ static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24
     lap("prove_assembly_ms");
     ctx->stats["prove_calls"] += 1;
     return VSP_OK;
+}
+
+
+// ---- a BATCH of proofs over one key (round 4).  Proofs of the real circuit's size (2^15..2^16 constraints) are bound by
+// the latency of their dependent chains -- a few hundred small launches, each a fraction of the GPU -- not by work: 2.1 ms per proof, 465 / s
+// from one context, ~900 / s from twelve.  K witnesses proved TOGETHER run the same number of launches K times as wide: one matvec, one
+// witness_map over 3 K transforms, and each of the five multi-exponentiations once over K scalar vectors (MsmGeom.K: separate bucket sets
+// per witness, the same base rows).  Every proof is byte-identical to vsp_groth16_prove's for the same (witness, r, s).
+// PLAIN key (vsp_groth16_generate with precompute = 0, or vsp_pk_create over plain bases): a batch has no use for tables of window multiples.
+static void prove_batch_cleanup(vsp_ctx *ctx, int rc) {
+    if (rc != VSP_OK) { std::string keep = ctx->err; msm_drain_slots(ctx); ctx->err = keep; }
+    for (unsigned k = 1; k <= 4; k++) (void)msm_slot_use_stream(ctx, k, nullptr);
+    if (ctx->pr_bz.p) hipMemsetAsync(ctx->pr_bz.p, 0, ctx->pr_bz.cap, ctx->stream);      // the witnesses do not outlive the call in device memory
+}
+static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t K, const uint64_t *r, const uint64_t *s,
+                            uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+    const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints, m = cs->dom.m, zs = nv + 1;
+    if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
+        return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
+    if (pk->A->pre_c || pk->B1->pre_c || pk->B2->pre_c || pk->H->pre_c || pk->L->pre_c)
+        return set_error(ctx, VSP_ERR_UNSUPPORTED, "prove_batch: needs a plain key (no tables of window multiples)");
+    VSP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    VSP_TRY(ensure(ctx, ctx->pr_bz, K * zs * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_babc, K * 3 * m * sizeof(Fr)));
+    VSP_TRY(ensure(ctx, ctx->pr_bh, K * m * sizeof(Fr)));
+    Fr *dz = (Fr *)ctx->pr_bz.p, *abc = (Fr *)ctx->pr_babc.p, *dH = (Fr *)ctx->pr_bh.p;
+    // z_k = (1, witness_k), canonical: the K ones from a small host array, the witnesses by one strided copy
+    std::vector<uint64_t> ones(K * 4, 0); for (size_t k = 0; k < K; k++) ones[4 * k] = 1;
+    VSP_HIP(hipMemcpy2DAsync(dz, zs * 32, ones.data(), 32, 32, K, hipMemcpyHostToDevice, st));
+    VSP_HIP(hipMemcpy2DAsync(dz + 1, zs * 32, witnesses, nv * 32, nv * 32, K, hipMemcpyHostToDevice, st));
+    VSP_HIP(hipMemsetAsync(abc, 0, K * 3 * m * sizeof(Fr), st));
+    if (nc) for (int j = 0; j < 3; j++) {
+        hipLaunchKernelGGL(k_csr_matvec, dim3((unsigned)((nc + 255) / 256), (unsigned)K), dim3(256), 0, st, (const uint32_t *)cs->rp[j], (const uint32_t *)cs->ci[j],
+                           (const Fr *)cs->co[j], (const Fr *)dz, nc, abc + (size_t)j * m, zs, 3 * m);
+        VSP_LAUNCH_CHECK();
+    }
+    VSP_HIP(hipMemcpy2DAsync(abc + nc, 3 * m * sizeof(Fr), dz, zs * sizeof(Fr), (ni + 1) * sizeof(Fr), K, hipMemcpyDeviceToDevice, st));      // the rows "input_i * 0 = 0" of A
+    VSP_HIP(hipStreamSynchronize(st));                       // `ones` goes out of scope; the copies above are queued from pageable memory anyway
+    // the four witness multi-exponentiations as two chains on the prover's two low-priority streams, the H chain on the context's (prove_launch_impl)
+    for (int k = 0; k < 2; k++) if (!ctx->prove_streams[k]) VSP_TRY(msm_make_slot_stream(ctx, &ctx->prove_streams[k]));
+    VSP_TRY(msm_slot_use_stream(ctx, 1, ctx->prove_streams[0])); VSP_TRY(msm_slot_use_stream(ctx, 2, ctx->prove_streams[0]));
+    VSP_TRY(msm_slot_use_stream(ctx, 3, ctx->prove_streams[1])); VSP_TRY(msm_slot_use_stream(ctx, 4, ctx->prove_streams[1]));
+    VSP_TRY(witness_map_device_batch(ctx, abc, (unsigned)K, &cs->dom, dH));
+    VSP_TRY(launch_on_bases_batch(ctx, 0, pk->H, 0, m - 1, dH, (unsigned)K, m, true));           // H coefficients are dense
+    VSP_TRY(launch_on_bases_batch(ctx, 1, pk->A, 0, nv + 1, dz, (unsigned)K, zs, false));
+    VSP_TRY(launch_on_bases_batch(ctx, 3, pk->B2, 0, nv + 1, dz, (unsigned)K, zs, false));
+    VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false));
+    VSP_TRY(launch_on_bases_batch(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, (unsigned)K, zs, false));
+    // host work that needs no result: the delta multiples of every proof
+    XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
+    XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
+    std::vector<XYZZ<HFp>> r_delta(K), s_delta(K), neg_rs_delta(K);
+    std::vector<XYZZ<HFp2>> s_delta2(K);
+    host_parallel_for(K, [&](size_t k) {
+        const uint64_t *rk = r + 4 * k, *sk = s + 4 * k;
+        uint64_t rs4[4]; host_store_canon(rs4, mul(host_load_canon<HFr>(rk), host_load_canon<HFr>(sk)));
+        r_delta[k] = xyzz_mul_scalar(dj, rk, 255); s_delta[k] = xyzz_mul_scalar(dj, sk, 255);
+        neg_rs_delta[k] = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
+        s_delta2[k] = xyzz_mul_scalar(dj2, sk, 255);
+    });
+    std::vector<XYZZ<HFp>> eA(K), eB1(K), eH(K), eL(K);
+    std::vector<XYZZ<HFp2>> eB2(K);
+    VSP_TRY(msm_g1_finish_batch(ctx, 1, eA.data(), (unsigned)K));
+    VSP_TRY(msm_g1_finish_batch(ctx, 2, eB1.data(), (unsigned)K));
+    VSP_TRY(msm_g1_finish_batch(ctx, 4, eL.data(), (unsigned)K));
+    VSP_TRY(msm_g2_finish_batch(ctx, 3, eB2.data(), (unsigned)K));
+    // s * A and r * B1 of every proof inside the wait for the H chain (prove_finish_impl, prove_early_assembly)
+    std::vector<XYZZ<HFp>> gA(K), s_gA(K), r_gB1(K);
+    host_parallel_for(K, [&](size_t k) {
+        gA[k] = eA[k]; xyzz_madd(gA[k], pk->alpha_g1); xyzz_add(gA[k], r_delta[k]);
+        s_gA[k] = xyzz_mul_scalar(gA[k], s + 4 * k, 255);
+        XYZZ<HFp> gB1 = eB1[k]; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta[k]);
+        r_gB1[k] = xyzz_mul_scalar(gB1, r + 4 * k, 255);
+    });
+    VSP_TRY(msm_g1_finish_batch(ctx, 0, eH.data(), (unsigned)K));
+    host_parallel_for(K, [&](size_t k) {
+        XYZZ<HFp2> gB2 = eB2[k]; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2[k]);
+        XYZZ<HFp> gC = eH[k]; xyzz_add(gC, eL[k]);
+        xyzz_add(gC, s_gA[k]); xyzz_add(gC, r_gB1[k]); xyzz_add(gC, neg_rs_delta[k]);
+        Affine<HFp> a = xyzz_to_affine(gA[k]), c = xyzz_to_affine(gC);
+        Affine<HFp2> b = xyzz_to_affine(gB2);
+        uint64_t A12[12], B24[24], C12[12];
+        host_store_g1(A12, a); host_store_g2(B24, b); host_store_g1(C12, c);
+        if (A_out) memcpy(A_out + 12 * k, A12, sizeof A12);
+        if (B_out) memcpy(B_out + 24 * k, B24, sizeof B24);
+        if (C_out) memcpy(C_out + 12 * k, C12, sizeof C12);
+        if (proofs_out) { vsp_g1_compress(A12, proofs_out + 192 * k); vsp_g2_compress(B24, proofs_out + 192 * k + 48); vsp_g1_compress(C12, proofs_out + 192 * k + 144); }
+    });
+    ctx->stats["prove_calls"] += (double)K;
+    ctx->stats["prove_batches"] += 1;
+    return VSP_OK;
+}
+int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count, const uint64_t *r, const uint64_t *s,
+                            uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!cs || !pk || !witnesses || !r || !s || count < 1 || count > 64) return set_error(ctx, VSP_ERR_ARG, "prove_batch: null argument or a batch outside 1..64");
+    if (ctx->prove.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
+    for (size_t k = 0; k < count; k++)
+        if (!fr_canonical(r + 4 * k) || !fr_canonical(s + 4 * k)) return set_error(ctx, VSP_ERR_ARG, "prove: r and s must be canonical (< r)");
+    int rc = prove_batch_impl(ctx, cs, pk, witnesses, count, r, s, A_out, B_out, C_out, proofs_out);
+    prove_batch_cleanup(ctx, rc);
+    return rc;
 }
 
 }  // extern "C"
