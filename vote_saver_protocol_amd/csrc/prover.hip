@@ -375,35 +375,57 @@ static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char *name) { double t = now(); ctx->stats[name] += t - t_prev; t_prev = t; };
-    XYZZ<HFp> eA, eB1, eH, eL; XYZZ<HFp2> eB2;
-    // host work that needs no MSM result, done while the GPU runs
+    XYZZ<HFp> eA = XYZZ<HFp>::inf(), eB1 = XYZZ<HFp>::inf(), eH = XYZZ<HFp>::inf(), eL = XYZZ<HFp>::inf(); XYZZ<HFp2> eB2 = XYZZ<HFp2>::inf();
+    // host work that needs no MSM result, done while the GPU runs: the four multiples of delta on four host threads (round 4: at the real
+    // circuit's size the HOST was the critical path of a proof -- 0.85 ms of scalar multiplications here and ~1 ms of Horner chains in the
+    // five finishes below, one after the other, against ~1.5 ms of GPU work; tools/prove_phases.py)
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
     HFr rr = host_load_canon<HFr>(r), ss = host_load_canon<HFr>(s);
     uint64_t rs4[4]; host_store_canon(rs4, mul(rr, ss));
-    XYZZ<HFp> r_delta = xyzz_mul_scalar(dj, r, 255), s_delta = xyzz_mul_scalar(dj, s, 255);
-    XYZZ<HFp> neg_rs_delta = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
-    XYZZ<HFp2> s_delta2 = xyzz_mul_scalar(dj2, s, 255);
-    XYZZ<HFp> saver = XYZZ<HFp>::inf();
-    if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
+    XYZZ<HFp> r_delta, s_delta, neg_rs_delta, saver = XYZZ<HFp>::inf();
+    XYZZ<HFp2> s_delta2;
+    long hthreads = 1; { auto it = ctx->opts.find("prove_host_threads"); if (it != ctx->opts.end()) hthreads = it->second; }
+    const unsigned T = hthreads ? 8u : 1u;
+    host_parallel_for(5, [&](size_t j) {
+        if (j == 0) s_delta2 = xyzz_mul_scalar(dj2, s, 255);                 // the G2 one is the longest: first
+        else if (j == 1) r_delta = xyzz_mul_scalar(dj, r, 255);
+        else if (j == 2) s_delta = xyzz_mul_scalar(dj, s, 255);
+        else if (j == 3) neg_rs_delta = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
+        else if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
+    }, T);
     if (overlap && *overlap) (*overlap)();
     lap("prove_host_overlap_ms");
-    // The witness multi-exponentiations finish long before the H chain (witness_map, then the dense H query): the two 255-bit scalar
-    // multiplications of the assembly, s * A and r * B1 (0.3 ms of host time), are done as soon as their operands exist, inside the wait
-    long early = 1; { auto it = ctx->opts.find("prove_early_assembly"); if (it != ctx->opts.end()) early = it->second; }
+    // The witness multi-exponentiations finish long before the H chain (witness_map, then the dense H query).  Each finish is a wait (this
+    // thread: it touches the context) and a fold of the window results -- a Horner chain of a few hundred host group operations, 0.2 ms in G1,
+    // 0.6 ms in G2 -- which runs on a thread of its own while this one waits for the next slot; s * A and r * B1, the two 255-bit scalar
+    // multiplications of the assembly, follow their folds on the same threads.  Option "prove_host_threads" = 0: everything on this thread.
     XYZZ<HFp> gA, gB1, s_gA, r_gB1;
-    VSP_TRY(msm_g1_finish(ctx, 1, &eA));
-    gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta);
-    if (early) s_gA = xyzz_mul_scalar(gA, s, 255);
-    VSP_TRY(msm_g1_finish(ctx, 2, &eB1));
-    gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta);
-    if (early) r_gB1 = xyzz_mul_scalar(gB1, r, 255);
-    VSP_TRY(msm_g1_finish(ctx, 4, &eL));
-    VSP_TRY(msm_g2_finish(ctx, 3, &eB2));
-    XYZZ<HFp2> gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2);
-    VSP_TRY(msm_g1_finish(ctx, 0, &eH));
+    XYZZ<HFp2> gB2;
+    std::vector<std::thread> workers;
+    auto run = [&](std::function<void()> f) { if (T > 1) workers.emplace_back(std::move(f)); else f(); };
+    auto join_all = [&]() { for (auto &w : workers) w.join(); workers.clear(); };
+    int rc = VSP_OK; bool empty = false;
+    if ((rc = msm_g1_finish_wait(ctx, 1, &empty)) == VSP_OK) {
+        const bool e = empty;
+        run([&, e]() { if (!e) msm_g1_fold(ctx, 1, &eA); gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta); s_gA = xyzz_mul_scalar(gA, s, 255); });
+    }
+    if (rc == VSP_OK && (rc = msm_g1_finish_wait(ctx, 2, &empty)) == VSP_OK) {
+        const bool e = empty;
+        run([&, e]() { if (!e) msm_g1_fold(ctx, 2, &eB1); gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta); r_gB1 = xyzz_mul_scalar(gB1, r, 255); });
+    }
+    if (rc == VSP_OK && (rc = msm_g1_finish_wait(ctx, 4, &empty)) == VSP_OK) {
+        const bool e = empty;
+        run([&, e]() { if (!e) msm_g1_fold(ctx, 4, &eL); });
+    }
+    if (rc == VSP_OK && (rc = msm_g2_finish_wait(ctx, 3, &empty)) == VSP_OK) {
+        const bool e = empty;
+        run([&, e]() { if (!e) msm_g2_fold(ctx, 3, &eB2); gB2 = eB2; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2); });
+    }
+    if (rc == VSP_OK && (rc = msm_g1_finish_wait(ctx, 0, &empty)) == VSP_OK && !empty) msm_g1_fold(ctx, 0, &eH);
+    join_all();
+    if (rc != VSP_OK) return rc;
     lap("prove_wait_ms");
-    if (!early) { s_gA = xyzz_mul_scalar(gA, s, 255); r_gB1 = xyzz_mul_scalar(gB1, r, 255); }
     // assembly: a handful of group operations
     XYZZ<HFp> gC = eH; xyzz_add(gC, eL);
     xyzz_add(gC, s_gA);
