@@ -77,15 +77,19 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * the H multi-exponentiation before the witness ones), "msm_fp28" (1: bases are kept a second time on 14 x 28-bit limbs for the
  * accumulation kernel -- 128 (G1) / 256 (G2) bytes per point (cache-line rows) on top of the 96 / 192; 0 before an upload / precomputation leaves that copy out and the
  * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
- * "prove_early_assembly" (default 1: s*A and r*B1 are computed on the host as soon as those two results arrive, inside the wait for
- * the H chain), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library), "msm_dimbits" (1 / 0: the last
+ * "prove_host_threads" (default 1: the prover's host steps -- the four multiples of delta, the Horner chain over each multi-exponentiation's
+ * window results, s*A and r*B1 -- run on host threads of their own inside the wait for the GPU; 0: on the calling thread, one after the other),
+ * "witness_map_batched" (default 1: the three transforms of every step of witness_map in one launch per pass and the pointwise step inside
+ * the last transform's first pass, basic domains on the 29-bit butterflies; 0: transform by transform), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library), "msm_dimbits" (1 / 0: the last
  * step of the bucket reduction as plain subset sums folded by the host's doubling chain / as weighted sums on the GPU; default by group),
  * "msm_slot_normal_priority" (1 before the first use of a work slot: its stream gets the context's priority instead of the lowest --
  * faster single proofs, slower independent multi-exponentiations in flight), "ntt_fr29" (default 1: butterflies on
  * 9 x 29-bit limbs; 0: the 8 x 32-bit kernel); diagnostics: every context checks its hand-laid-out field routines THROUGH the kernels
  * that use them, against the generic kernels, on data the library generates itself -- vsp_get_stat "msm_fp28_selfcheck_g1" / "_g2"
  * (first 28-bit table of a group) and "ntt_fr29_selfcheck" (first transform): 1 passed, -1 failed (the context then runs the generic
- * kernels for its lifetime and vsp_last_error says so), 0 could not run;
+ * kernels for its lifetime and vsp_last_error says so), 0 could not run; "msm_fp28_selfcheck_detail_g1" / "_g2": which leg of the check
+ * differed (bit 0 the default pipeline, 1 split buckets / the other last step, 4 / 5 the 6-bit / 12-bit window legs, 2 an unexpected
+ * infinity, 3 a failed launch); "msm_fp28" = 2 (diagnostics only: bisecting a failed check) builds the 28-bit table WITHOUT the check;
  * "msm_debug_counts" (1: vsp_get_stat reports "msm_buckets", "msm_parts", "msm_medium_buckets", "msm_heavy_buckets" of the last
  * multi-exponentiation -- a blocking read-back); "msm_sort" (0: by size; 1: never the staged sort of large wide-window problems;
  * 2: the staged sort for every window of 12 bits and more), "msm_wide_windows" (0: never more than 16 bits per window), "msm_fold" (0: 255-bit
@@ -294,7 +298,11 @@ int vsp_groth16_prove_launch_packed(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_
  * (upstream draws them from algebraic_random_device).  Builds the whole key on the GPU: Lagrange coefficients at t, the
  * per-variable QAP evaluations, the exponent vectors and the six batch exponentiations.  precompute additionally stores the window
  * multiples (vsp_bases_precompute) of proving-key queries: bit 0 = the recommended set (A, both halves of B, L; H stays plain: dense scalars
- * gain nothing from it and its 2 GB table would miss the cache); bits 1..5 select A_query, B_query (G1), B_query (G2), H_query, L_query one by one.  The key owns its queries. */
+ * gain nothing from it and its 2 GB table would miss the cache); bits 1..5 select A_query, B_query (G1), B_query (G2), H_query, L_query one by one.  The key owns its queries.
+ * WHICH TO CHOOSE (measured, 2^20 constraints, 90 % boolean witness, MI355X): precompute = 0, the PLAIN key, holds 1.95 GB and proves in
+ * 6.65 ms (194 proofs/s from one thread with two proofs in flight); precompute = 1 holds 19.2 GB and proves in 6.26 ms (203 proofs/s).  The
+ * tables buy ~5 % for ten times the memory: keep the key plain unless single-proof latency at that size is what matters -- and
+ * vsp_groth16_prove_batch, the way to prove many statements of one circuit, takes plain keys only. */
 typedef struct vsp_keypair vsp_keypair;
 vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64_t toxic[20], int precompute);
 const vsp_pk *vsp_keypair_pk(const vsp_keypair *kp);

@@ -88,7 +88,7 @@ int main() {
         std::vector<proving_key<curve>::g1_value_type> bases{g, g};
         std::vector<fr> scalars{fr(fr::integral_type(1)), fr(fr::integral_type(1))};
         auto two_g = algebra::multiexp<algebra::policies::multiexp_method_BDLO12>(bases.begin(), bases.end(), scalars.begin(), scalars.end(), 1);
-        const bool ok = static_cast<std::uint64_t>(two_g.to_affine().X.data) == 0x2ff2d1e9cd4f3f55ULL || true;      // value checked by the caller against the oracle
+        const bool ok = static_cast<std::uint64_t>(two_g.to_affine().X.data) == 0xc39a8c5529bf0f4eULL;      // low word of (2 G).x; the caller compares the printed value with the oracle's as well
         std::printf("2G.x[0] = %016llx\n", (unsigned long long)static_cast<std::uint64_t>(two_g.to_affine().X.data));
         // instantiate the whole loop (never run here: the stand-in has no arithmetic to make a satisfying instance from)
         if (bases.empty()) {
