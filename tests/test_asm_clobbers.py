@@ -15,3 +15,21 @@ def test_every_register_a_routine_writes_is_declared_where_it_is_entered():
     assert len(lines) >= 7 and all("undeclared writes: none" in x and "input-only operands written: none" in x for x in lines)
     for label in ("vsp_mm_12", "vsp_mm_8", "vsp_mm28", "vsp_sq28", "vsp_mm28x2", "vsp_mm29", "vsp_acc28"):
         assert any(("entered at " + label + ":") in x for x in lines), label
+
+
+def test_no_read_of_a_clobbered_register_after_a_routine_entry_in_the_generated_isa(tmp_path):
+    """the other side of the interface (round 4, tools/check_call_sites.py): in the ISA the compiler generates for the 28-bit MSM kernels
+    (msm_g1.hip, shipped flags), no instruction reads a register that a routine entry before it clobbered and nothing has rewritten --
+    linear scan between labels, 30+ kernels with routine entries"""
+    import shutil
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path / "msm_g1.s")
+    csrc = os.path.join(ROOT, "vote_saver_protocol_amd", "csrc")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-unused-value",
+                           "-Wno-unused-result", "-mllvm", "-enable-misched=0", "--cuda-device-only", "-S", "msm_g1.hip", "-o", out], cwd=csrc, stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_call_sites.py"), out], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 suspicious read(s)" in r.stdout, r.stdout[-2000:]
+    assert int(r.stdout.split("check_call_sites: ")[1].split(" ")[0]) >= 20

@@ -226,3 +226,55 @@ def test_r1cs_upload_refuses_null_arrays_and_bad_row_pointers(ctx):
     h = lib.vsp_r1cs_upload(ctx.h, 2, 1, 2, p(rp0), None, None, *(good * 2))
     assert h
     lib.vsp_r1cs_free(ctx.h, h)
+
+
+def test_batch_entry_points_validate_every_vector_and_recover(ctx, cref):
+    """vsp_msm_resident_batch / vsp_groth16_prove_batch (round 4): a scalar >= r in ANY vector of a batch is refused (the census counts the
+    vectors together), batch sizes outside 1..64 and strides shorter than a vector are refused, a batch of one equals the single call,
+    the largest batch works, and after every refusal the context proves again"""
+    import bls12_381 as o
+    from conftest import L, fr_array
+    n, K = 5000, 6
+    bases = cref.g1_batch_mul_gen(rand_fr_array(n, 15))
+    vecs = np.stack([rand_fr_array(n, 20 + k) for k in range(K)])
+    B = ctx.upload_bases(bases, 1)
+    d_s = ctx.to_device(vecs.reshape(-1, 4))
+    got, _ = B.msm_batch(d_s, K)
+    for k in range(K):
+        assert np.array_equal(got[k], cref.msm_g1(bases, vecs[k]))
+    one, _ = B.msm_batch(d_s, 1)
+    assert np.array_equal(one[0], B.msm(d_s)[0])
+    for k_bad in (0, 3, K - 1):                                               # a non-canonical scalar in the first, a middle, the last vector
+        bad = vecs.copy(); bad[k_bad, 4321] = L(o.R, 4)
+        ctx.h2d(d_s, bad.reshape(-1, 4))
+        with pytest.raises(v.VspError, match="canonical"):
+            B.msm_batch(d_s, K)
+    ctx.h2d(d_s, vecs.reshape(-1, 4))
+    assert np.array_equal(B.msm_batch(d_s, K)[0], got)                        # the slot recovers
+    for bad_K, stride in ((0, n), (65, n), (2, n - 1)):
+        with pytest.raises(v.VspError):
+            B.msm_batch(d_s, bad_K, stride=stride)
+    small = cref.g1_batch_mul_gen(rand_fr_array(40, 16)); sv = np.stack([rand_fr_array(40, 50 + k) for k in range(64)])
+    Bs = ctx.upload_bases(small, 1); d_sv = ctx.to_device(sv.reshape(-1, 4))
+    g64, _ = Bs.msm_batch(d_sv, 64)
+    assert all(np.array_equal(g64[k], cref.msm_g1(small, sv[k])) for k in range(64))
+    Bs.free(); ctx.dfree(d_sv); B.free(); ctx.dfree(d_s)
+    # the prover
+    gen = o.splitmix64(19)
+    cs, wit = cref.R1CS.synth(700, 4, 19)
+    tox = fr_array([o.rand_fr(gen) for _ in range(5)])
+    dcs = v.R1CS(ctx, 700, 4, cs.num_vars, *cs.export())
+    kp = v.Keypair(ctx, dcs, tox)
+    r, s = L(o.rand_fr(gen), 4), L(o.rand_fr(gen), 4)
+    ok = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)
+    W = np.stack([wit, wit, wit]); R = np.stack([r, r, r]); S = np.stack([s, s, s])
+    assert v.groth16_prove_batch(ctx, dcs, kp.pk, W, R, S)[3] == [ok[3]] * 3
+    R2 = R.copy(); R2[2] = L(o.R, 4)
+    with pytest.raises(v.VspError, match="canonical"):
+        v.groth16_prove_batch(ctx, dcs, kp.pk, W, R2, S)
+    W2 = W.copy(); W2[1, 77] = L(o.R + 1, 4)
+    with pytest.raises(v.VspError, match="canonical"):                         # found by the census of the batch, every slot drained
+        v.groth16_prove_batch(ctx, dcs, kp.pk, W2, R, S)
+    assert v.groth16_prove_batch(ctx, dcs, kp.pk, W, R, S)[3] == [ok[3]] * 3
+    assert v.groth16_prove(ctx, dcs, kp.pk, wit, r, s)[3] == ok[3]
+    kp.free(); dcs.free(); cs.free()
