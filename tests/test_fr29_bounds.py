@@ -246,3 +246,32 @@ def test_the_model_notices_a_broken_bound():
         sub29(tight(5), tight(2 * R + 5))
     with pytest.raises(Bound):
         b_mul(B(RP, [1 << 32] * N), B.tight(R))
+
+
+def test_fused_pointwise_load_of_witness_map_stays_inside_the_lazy_domain():
+    """round 4: the first pass of witness_map's last transform computes its own input, (a b - c) / 2^261, from canonical a, b, c
+    (k_ntt29_pass, NttPass29Args.fuse_b / fuse_c): two products of tight operands, the lazy subtraction (its subtrahend IS a product
+    output), one carry pass.  Exact model on edge and random values against plain integers; then the worst-case propagation of a whole
+    transform starting from that bound (3.03 r instead of a canonical input's 1.02 r) -- 11 steps (2^22) and 14 (2^28) keep every constraint."""
+    rng = random.Random(29)
+    one = [1] + [0] * (N - 1)
+    rinv = pow(RP, -1, R)
+    edge = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (1 << 254) - 1, (1 << 29) - 1, 1 << 29]
+    cases = [(a, b, c) for a in edge for b in edge for c in edge] + [(rng.randrange(R), rng.randrange(R), rng.randrange(R)) for _ in range(300)]
+    worst = 0
+    for a, b, c in cases:
+        v = norm29(sub29(mm29(tight(a), tight(b)), mm29(tight(c), one)))
+        assert val(v) % R == (a * b - c) * rinv % R
+        assert all(x <= MASK for x in v[:-1])
+        worst = max(worst, val(v))
+    assert worst < 3.03 * R
+    w = B.tight(R)
+    for steps in (11, 14):
+        V = B.tight(int(3.03 * R))
+        for step in range(steps):
+            x1 = b_mul(V, w); assert x1.v < 1.9 * R
+            a0, a1 = b_add(V, x1), b_sub(V, x1)
+            p2, p3 = b_mul(a0, w), b_mul(a1, w); assert p3.v < 1.9 * R
+            outs = [b_norm(b_add(a0, p2)), b_norm(b_add(a1, p3)), b_norm(b_sub(a0, p2)), b_norm(b_sub(a1, p3))]
+            V = B.tight(max(x.v for x in outs))
+        assert V.v < RP and b_mul(V, w).v < 2 * R

@@ -198,7 +198,11 @@ template <class P> __device__ __forceinline__ Mont<P> mul_comba(const Mont<P> &a
 template <class P> __attribute__((noinline)) Mont<P> mul_host(const Mont<P> &a, const Mont<P> &b) { return mul_cios<P>(a, b); }
 
 template <class P> VSP_HD Mont<P> mul(const Mont<P> &a, const Mont<P> &b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(VSP_PORTABLE_MUL)
+    // DIAGNOSTIC BUILD (`make portable`): no hand-laid-out routine anywhere -- the compiler's own code for every field product, so that a
+    // result can be cross-checked against a library in which the routine / compiler interface does not exist (missing 3)
+    return mul_cios<P>(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     if constexpr (sizeof(typename P::limb_t) == 4) return mul_comba<P>(a, b);
     else return mul_cios<P>(a, b);          // 64-bit-limb (host) types are never run on the device
 #else

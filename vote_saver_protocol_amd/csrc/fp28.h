@@ -48,6 +48,34 @@ __device__ __forceinline__ Fp28 fp28_const(const uint32_t (&c)[14]) { Fp28 r; fo
 __device__ __forceinline__ bool fp28_all_zero(const Fp28 &a) { uint32_t o = 0; for (int i = 0; i < 14; i++) o |= a.l[i]; return o == 0; }
 __device__ __forceinline__ bool fp28_equals(const Fp28 &a, const uint32_t (&c)[14]) { uint32_t o = 0; for (int i = 0; i < 14; i++) o |= a.l[i] ^ c[i]; return o == 0; }
 
+#if defined(VSP_PORTABLE_MUL)
+// DIAGNOSTIC BUILD (`make portable`): the same column schedule as the generated routines (tools/gen_mont_asm.py body28) in plain C++ -- one
+// 64-bit accumulator per column, m_k = (acc * (-1/p mod 2^28)) mod 2^28, no final subtraction -- as real functions (inlined they make the
+// translation unit take tens of minutes to compile).  Bit-identical outputs by construction: the same column totals.
+__device__ __noinline__ void mont28_portable(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d) {
+    uint32_t m[14];
+    uint64_t acc = 0;
+    for (int k = 0; k < 27; k++) {
+        for (int i = (k > 13 ? k - 13 : 0); i <= (k < 13 ? k : 13); i++) {
+            acc += (uint64_t)a[i] * b[k - i];
+            if (c) acc += (uint64_t)c[i] * d[k - i];
+        }
+        if (k < 14) {
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FP28_P[k - i];
+            m[k] = ((uint32_t)acc * 0xffcfffdu) & 0x0FFFFFFFu;
+            acc += (uint64_t)m[k] * FP28_P[0];
+        } else {
+            for (int i = k - 13; i < 14; i++) acc += (uint64_t)m[i] * FP28_P[k - i];
+            r[k - 14] = (uint32_t)acc & 0x0FFFFFFFu;
+        }
+        acc >>= 28;
+    }
+    r[13] = (uint32_t)acc;
+}
+__device__ __forceinline__ Fp28 mul28(const Fp28 &a, const Fp28 &b) { Fp28 r; mont28_portable(r.l, a.l, b.l, nullptr, nullptr); return r; }
+__device__ __forceinline__ Fp28 sqr28(const Fp28 &a) { Fp28 r; mont28_portable(r.l, a.l, a.l, nullptr, nullptr); return r; }
+__device__ __forceinline__ Fp28 mul28x2(const Fp28 &a, const Fp28 &b, const Fp28 &c, const Fp28 &d) { Fp28 r; mont28_portable(r.l, a.l, b.l, c.l, d.l); return r; }
+#else
 __device__ __forceinline__ Fp28 mul28(const Fp28 &a, const Fp28 &b) {
     Fp28 r;
     __builtin_amdgcn_sched_barrier(0);          // the machine scheduler of this toolchain crashes when it moves code across the call
@@ -78,6 +106,7 @@ __device__ __forceinline__ Fp28 mul28x2(const Fp28 &a, const Fp28 &b, const Fp28
     (void)&mont_mul28x2_holder<0>;
     return r;
 }
+#endif
 // a + K - b, limb by limb (see the header for which K goes with which b)
 __device__ __forceinline__ Fp28 sub28(const Fp28 &a, const uint32_t (&K)[14], const Fp28 &b) {
     Fp28 r;

@@ -55,6 +55,27 @@ __device__ __forceinline__ Fr fr29_to_words(const Fr29 &v) {
     }
     return c;
 }
+#if defined(VSP_PORTABLE_MUL)
+// DIAGNOSTIC BUILD (`make portable`): vsp_mm29's column schedule in plain C++ (r = 1 mod 2^32 makes m_k the negated column)
+__device__ __noinline__ void mont29_portable(uint32_t *r, const uint32_t *a, const uint32_t *b) {
+    uint32_t m[9];
+    uint64_t acc = 0;
+    for (int k = 0; k < 17; k++) {
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) acc += (uint64_t)a[i] * b[k - i];
+        if (k < 9) {
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FR29_R[k - i];
+            m[k] = (0u - (uint32_t)acc) & FR29_MASK;
+            acc += (uint64_t)m[k] * FR29_R[0];
+        } else {
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * FR29_R[k - i];
+            r[k - 9] = (uint32_t)acc & FR29_MASK;
+        }
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+}
+__device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) { Fr29 r; mont29_portable(r.l, a.l, b.l); return r; }
+#else
 __device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) {
     Fr29 r;
     __builtin_amdgcn_sched_barrier(0);          // as fp28.h: this toolchain's machine scheduler must not move code across the call
@@ -63,6 +84,7 @@ __device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) {
     (void)&mont_mul29_holder<0>;
     return r;
 }
+#endif
 __device__ __forceinline__ Fr29 add29(const Fr29 &a, const Fr29 &b) {
     Fr29 r;
 #pragma unroll

@@ -24,6 +24,7 @@
 //  * Coset shift (a[j] *= g^j), inverse scaling (m^-1) and inverse coset shift are fused into the
 //    first pass's load / the last pass's store.
 //  * The path is integer-ALU bound (one 8-limb Montgomery product per butterfly), not HBM bound.
+#include <algorithm>
 #include "common.h"
 #include "fr29.h"
 
@@ -193,7 +194,7 @@ __device__ __forceinline__ void lds_store29(uint4 *pl0, uint4 *pl1, uint32_t *pl
 }
 
 #ifdef VSP_DIAG_CLOCK
-__device__ unsigned long long vsp_diag_ntt_sums[4];          // shader cycles, 100 MHz ticks, waves (diagnostic build only)
+__device__ unsigned long long vsp_diag_ntt_sums[4096][4];    // per workgroup slot: shader cycles, 100 MHz ticks, waves (diagnostic build only; ONE address for all waves cost 390 us per pass)
 #endif
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, PlanesOut29 out_lazy, NttPass29Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, Pl
 #ifdef VSP_DIAG_CLOCK
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(dc_t1), "=s"(dc_r1) :: "memory");
     if ((threadIdx.x & 63u) == 0) {
-        atomicAdd(&vsp_diag_ntt_sums[0], dc_t1 - dc_t0); atomicAdd(&vsp_diag_ntt_sums[1], dc_r1 - dc_r0); atomicAdd(&vsp_diag_ntt_sums[2], 1ull);
+        unsigned long long *slot = vsp_diag_ntt_sums[(blockIdx.x + 2048u * blockIdx.y) & 4095u];
+        atomicAdd(&slot[0], dc_t1 - dc_t0); atomicAdd(&slot[1], dc_r1 - dc_r0); atomicAdd(&slot[2], 1ull);
     }
 #endif
 #endif
@@ -326,12 +328,14 @@ __global__ __launch_bounds__(256) void k_fill_twiddles(Fr *T, const Fr *A, const
 // diagnostic build: clock held inside the passes of the 29-bit transform since the last reset
 int ntt_diag_clock(vsp_ctx *ctx, int reset, double *ghz, double *waves) {
 #ifdef VSP_DIAG_CLOCK
-    unsigned long long h[4] = {0, 0, 0, 0};
+    std::vector<unsigned long long> all(4096 * 4, 0);
     VSP_HIP(hipStreamSynchronize(ctx->stream));
-    VSP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(vsp_diag_ntt_sums), sizeof h));
+    VSP_HIP(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(vsp_diag_ntt_sums), all.size() * sizeof(unsigned long long)));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < 4096; i++) for (int j = 0; j < 3; j++) h[j] += all[4 * i + j];
     if (ghz) *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
     if (waves) *waves = (double)h[2];
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; VSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vsp_diag_ntt_sums), z, sizeof z)); }
+    if (reset) { std::fill(all.begin(), all.end(), 0ull); VSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(vsp_diag_ntt_sums), all.data(), all.size() * sizeof(unsigned long long))); }
     return VSP_OK;
 #else
     (void)reset; if (ghz) *ghz = 0.0; if (waves) *waves = 0.0;
