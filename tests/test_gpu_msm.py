@@ -622,7 +622,8 @@ def test_msm_g2_2p21_config5_shard_plain_bases(ctx, cref):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("option,value", [("msm_dimbits", 0), ("msm_dimbits", 1), ("msm_dimsum_lanes", 8), ("msm_dimsum_lanes", 16),
-                                          ("msm_dimsum_lanes", 32), ("msm_dimsum_lanes", 64), ("msm_glv", 0), ("msm_glv", 2), ("msm_fp28", 0)])
+                                          ("msm_dimsum_lanes", 32), ("msm_dimsum_lanes", 64), ("msm_glv", 0), ("msm_glv", 2), ("msm_fp28", 0),
+                                          ("msm_dimsum_prefetch", 1)])
 def test_msm_same_result_under_every_kernel_variant_option(cref, option, value):
     """the tuning options of include/vsp.h pick kernel variants (lanes per bucket-digit sum, bit-decomposed or weighted last step of the
     bucket reduction, endomorphism split, 28-bit or 12 x 32-bit accumulation): every variant gives the oracle's point, on plain and on
@@ -696,3 +697,28 @@ def test_batch_of_scalar_vectors_over_one_set_of_bases(ctx, cref, group, n, K, k
         B.free()
     ctx.set_option("msm_glv", 1)
     ctx.dfree(d_s)
+
+
+@pytest.mark.parametrize("fp28", [1, 0])
+def test_prefetching_bucket_reduction_on_the_inputs_that_exposed_the_round3_finding(cref, fp28):
+    """option msm_dimsum_prefetch = 1 (k_dimsum_mixed with the next bucket record in flight): the loop round 3 measured WRONG on inputs whose
+    additions take the doubling path -- one point many times, two points, 34 / 200 / 300 entries, 5..13-bit windows (tools/dimsum_prefetch_probe.py)
+    -- because the toolchain's machine scheduler corrupted the compiler's liveness.  Built without that scheduler it must
+    give the oracle's point on exactly those inputs, on the generic and on the 28-bit form (n >= 1024 gets a 28-bit table)."""
+    c = v.Context(0)
+    try:
+        c.set_option("msm_dimsum_prefetch", 1); c.set_option("msm_fp28", fp28)
+        one = cref.g1_batch_mul_gen(rand_fr_array(1, seed=91))
+        many = cref.g1_batch_mul_gen(rand_fr_array(300, seed=93))
+        makers = {"one point": lambda n: np.repeat(one, n, axis=0), "distinct": lambda n: np.concatenate([many] * (n // 300 + 1))[:n].copy(),
+                  "two points": lambda n: np.concatenate([np.repeat(one, n // 2, axis=0), np.repeat(many[:1], n - n // 2, axis=0)])}
+        for label, mk in makers.items():
+            for n, wb in ((34, 8), (34, 5), (200, 8), (200, 11), (300, 13), (1500, 8), (1500, 11), (4096, 9)):
+                bases = mk(n); ss = rand_fr_array(n, seed=92 + n)
+                c.set_option("msm_window_bits", wb)
+                B = c.upload_bases(bases, 1); d_s = c.to_device(ss)
+                got, _ = B.msm(d_s)
+                assert np.array_equal(got, cref.msm_g1(bases, ss, mixed=True)), (label, n, wb, fp28)
+                B.free(); c.dfree(d_s)
+    finally:
+        c.close()

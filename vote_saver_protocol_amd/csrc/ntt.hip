@@ -175,7 +175,6 @@ struct NttPass29Args {
     // fused load of the first pass (witness_map's last transform): the value transformed is in[0][i] * fuse_b[i] - fuse_c[i], left with the
     // factor 2^-261 of the two products (the caller folds 2^261 into the scale); nullptr: plain load
     const Fr *fuse_b, *fuse_c;
-    unsigned stagger, stagger_shift;      // experiment (option "ntt_stagger"): workgroups with bit `stagger_shift` of their index set sleep stagger x 8128 cycles before they start
 };
 __device__ __forceinline__ Fr29 ld29(const Planes29 &t, size_t j) {
     Fr29 v; uint4 a = t.p0[j], b = t.p1[j];
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, Pl
     const Fr *__restrict__ in_words = p.in_stride ? p.in[0] + (size_t)blockIdx.y * p.in_stride : p.in[blockIdx.y];
     Fr *__restrict__ out_words = p.out_stride ? p.out[0] + (size_t)blockIdx.y * p.out_stride : p.out[blockIdx.y];
     const size_t fuse_off = (size_t)blockIdx.y * p.in_stride;      // the fused load's other two operands follow their transform
-    if (p.stagger && ((blockIdx.x >> p.stagger_shift) & 1u)) for (unsigned z = 0; z < p.stagger; z++) __builtin_amdgcn_s_sleep(127);
     { const size_t boff = (size_t)blockIdx.y << p.log_n;          // this transform's slice of the scratch planes
       in_lazy.p0 += boff; in_lazy.p1 += boff; in_lazy.p2 += boff; out_lazy.p0 += boff; out_lazy.p1 += boff; out_lazy.p2 += boff; }
 #ifdef VSP_DIAG_CLOCK
@@ -607,8 +605,6 @@ static int ntt_device_impl(vsp_ctx *ctx, const Fr *const *d_in, Fr *const *d_out
             if (in_stride || out_stride) { p.in[0] = d_in[0]; p.out[0] = d_out[0]; p.in_stride = in_stride; p.out_stride = out_stride; }
             else for (unsigned b = 0; b < count; b++) { p.in[b] = d_in[b]; p.out[b] = d_out[b]; }
             if (p.first) { p.fuse_b = fuse_b; p.fuse_c = fuse_c; }
-            { auto it = ctx->opts.find("ntt_stagger"); if (it != ctx->opts.end()) p.stagger = (unsigned)it->second; }
-            { auto it = ctx->opts.find("ntt_stagger_shift"); if (it != ctx->opts.end()) p.stagger_shift = (unsigned)it->second; }
             if (!p.first && p.s0 < p.clog) return set_error(ctx, VSP_ERR_UNSUPPORTED, "ntt: pass plan");
             const unsigned tile_log = stages[i] + p.clog;
             hipLaunchKernelGGL(k_ntt29_pass, dim3((unsigned)(n >> tile_log), count), dim3(NTT_THREADS), 0, ctx->stream, lazy_in, lazy_out, p);
