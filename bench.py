@@ -51,7 +51,7 @@ MADS_PER_ADD = {1: 6 * 392 + 2 * 301 + 588, 2: 2 * (8 * 588 + 2 * 392)}   # v_ma
 # tools/ubench_valu.hip, whose separate asm statements let the compiler put an s_nop after every multiply-add, and was priced in wall time at the nominal clock.)
 ISSUE_CYCLES_FALLBACK = {"mad": 4.59, "simple": 2.88}
 N_SIMD = 1024
-PMC_FILES = ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_h_pmc_hbm_traffic.json")   # newest first; see profiles/README.md
+PMC_FILES = ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_h_pmc_hbm_traffic.json")   # newest first; see profiles/README.md
 
 
 def rand_fr(n, seed):
