@@ -822,6 +822,8 @@ def main():
     ap.add_argument("--no-diag-clock", action="store_true", help="skip the 2 s in-kernel clock leg (diagnostic build of the library)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend of the exchange step: nccl = RCCL over xGMI (device buffers); gloo = host buffers (rehearsals)")
+    ap.add_argument("--force-replicas", action="store_true",
+                    help="rehearsal: run the N > 1 replica-proving leg at N = 1 too (under torch.distributed.run: its broadcasts and gathers then go through RCCL with one rank)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank g uses GPU g mod (GPUs present); forces --backend gloo (RCCL refuses two ranks on one GPU)")
     args = ap.parse_args()
@@ -1250,7 +1252,7 @@ def main():
     # =============================================================== proofs/s at N > 1: replica proving, every rank its own resident key
     # (N = 1: bench_prove above measures the same ring mode -- ONE host thread, three contexts, packed witness -- and much more)
     replicas = None
-    if world > 1 and not args.no_prove:
+    if (world > 1 or (args.force_replicas and use_dist)) and not args.no_prove:
         replicas = replica_leg(args, v, torch, dist, coll_dev, rank, world, dev_index, barrier, allmax, cref, o)
 
     # =============================================================== BASELINE config 5 in the same run: 2^26 G1 + 2^24 G2 over the ranks
@@ -1316,6 +1318,9 @@ def main():
                                  "verified": bool(c5["g1"]["verified"] and c5["g2"]["verified"]) if rank == 0 else None,
                                  "ranks_seen_by_rccl": ranks_seen if exchange.backend == "nccl" else None,
                                  "ranks_seen_by_collective": ranks_seen, "backend": exchange.backend, "n_gpus": world}
+    if replicas is not None and world == 1:          # --force-replicas rehearsal: reported beside the N = 1 figures, not instead of them
+        extras["prove_replicas_rehearsal"] = replicas
+        replicas = None
     if replicas is not None:                         # N > 1: the other half of BASELINE.json's metric from the replica leg
         out["secondary"] = {"metric": "Groth16 proofs/sec at 2^%d constraints (synthetic SAVER-shaped R1CS, pairing-verified), all GPUs" % args.prove_log_n,
                             "value": replicas["proofs_per_s"], "unit": "proofs/s", "n_gpus": world, "mode": replicas["mode"],
