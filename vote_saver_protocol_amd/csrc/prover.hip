@@ -466,6 +466,9 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
         return set_error(ctx, VSP_ERR_UNSUPPORTED, "prove_batch: needs a plain key (no tables of window multiples)");
     VSP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *name) { double t = now(); ctx->stats[name] += t - t_prev; t_prev = t; };      // vsp_get_stat "prove_batch_*_ms": where a batch's time goes on the host
     VSP_TRY(ensure(ctx, ctx->pr_bz, K * zs * sizeof(Fr)));
     VSP_TRY(ensure(ctx, ctx->pr_babc, K * 3 * m * sizeof(Fr)));
     VSP_TRY(ensure(ctx, ctx->pr_bh, K * m * sizeof(Fr)));
@@ -492,6 +495,7 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
     VSP_TRY(launch_on_bases_batch(ctx, 3, pk->B2, 0, nv + 1, dz, (unsigned)K, zs, false));
     VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false));
     VSP_TRY(launch_on_bases_batch(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, (unsigned)K, zs, false));
+    lap("prove_batch_launch_ms");
     // host work that needs no result: the delta multiples of every proof
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
@@ -504,12 +508,14 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
         neg_rs_delta[k] = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
         s_delta2[k] = xyzz_mul_scalar(dj2, sk, 255);
     });
+    lap("prove_batch_delta_ms");
     std::vector<XYZZ<HFp>> eA(K), eB1(K), eH(K), eL(K);
     std::vector<XYZZ<HFp2>> eB2(K);
     VSP_TRY(msm_g1_finish_batch(ctx, 1, eA.data(), (unsigned)K));
     VSP_TRY(msm_g1_finish_batch(ctx, 2, eB1.data(), (unsigned)K));
     VSP_TRY(msm_g1_finish_batch(ctx, 4, eL.data(), (unsigned)K));
     VSP_TRY(msm_g2_finish_batch(ctx, 3, eB2.data(), (unsigned)K));
+    lap("prove_batch_witness_finishes_ms");
     // s * A and r * B1 of every proof inside the wait for the H chain (prove_finish_impl, prove_early_assembly)
     std::vector<XYZZ<HFp>> gA(K), s_gA(K), r_gB1(K);
     host_parallel_for(K, [&](size_t k) {
@@ -518,7 +524,9 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
         XYZZ<HFp> gB1 = eB1[k]; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta[k]);
         r_gB1[k] = xyzz_mul_scalar(gB1, r + 4 * k, 255);
     });
+    lap("prove_batch_sA_rB1_ms");
     VSP_TRY(msm_g1_finish_batch(ctx, 0, eH.data(), (unsigned)K));
+    lap("prove_batch_h_finish_ms");
     host_parallel_for(K, [&](size_t k) {
         XYZZ<HFp2> gB2 = eB2[k]; xyzz_madd(gB2, pk->beta_g2); xyzz_add(gB2, s_delta2[k]);
         XYZZ<HFp> gC = eH[k]; xyzz_add(gC, eL[k]);
@@ -532,6 +540,7 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
         if (C_out) memcpy(C_out + 12 * k, C12, sizeof C12);
         if (proofs_out) { vsp_g1_compress(A12, proofs_out + 192 * k); vsp_g2_compress(B24, proofs_out + 192 * k + 48); vsp_g1_compress(C12, proofs_out + 192 * k + 144); }
     });
+    lap("prove_batch_assembly_ms");
     ctx->stats["prove_calls"] += (double)K;
     ctx->stats["prove_batches"] += 1;
     return VSP_OK;
