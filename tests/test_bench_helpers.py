@@ -93,3 +93,37 @@ def test_launcher_refuses_cleanly_without_gpus_and_never_imports_torch_first():
         pytest.skip("GPUs present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and r.stdout == "" and "nothing was launched" in r.stderr
+
+
+def test_prove_ring_keeps_one_proof_in_flight_per_context_and_finishes_every_launch():
+    """bench.prove_ring (the one-host-thread mode behind `secondary`): with a ring of C contexts, C - 1 proofs are in flight while one is
+    awaited, every context holds at most one proof, launches and finishes alternate in ring order, and exactly total + C - 1 proofs run"""
+    for C in (1, 2, 3, 4):
+        for total in (1, 5, 12):
+            log = []
+
+            class Ctx:
+                def __init__(self, i): self.i = i; self.busy = False
+
+            class V:
+                @staticmethod
+                def groth16_prove_launch(c, dcs, pk, src, r, s):
+                    assert not c.busy, "two proofs in flight on one context"
+                    c.busy = True; log.append(("L", c.i))
+
+                @staticmethod
+                def groth16_prove_finish(c):
+                    assert c.busy, "finish without launch"
+                    c.busy = False; log.append(("F", c.i)); return ("proof", c.i)
+
+            ring = [Ctx(i) for i in range(C)]
+            dt, last = bench.prove_ring(V, ring, None, None, None, None, None, total)
+            assert dt >= 0 and last[0] == "proof"
+            assert sum(1 for x in log if x[0] == "L") == total + C - 1 == sum(1 for x in log if x[0] == "F")
+            assert not any(c.busy for c in ring)
+            fin = [x[1] for x in log if x[0] == "F"]
+            assert fin == [k % C for k in range(total + C - 1)]                       # finishes in ring order
+            in_flight = 0; peak = 0
+            for kind, _ in log:
+                in_flight += 1 if kind == "L" else -1; peak = max(peak, in_flight)
+            assert peak == C
