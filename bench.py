@@ -182,6 +182,21 @@ def bench_prove_small(ctx, v, cref, o, log_m=16, precompute=True):
             for x in thb: x.start()
             for x in thb: x.join()
             multi[f"{C_}_contexts_x_batch_{K}"] = C_ * reps_m * K / (time.perf_counter() - t0)
+        # ONE host thread, a batch in flight on each of two contexts (vsp_groth16_prove_batch_launch / _finish): it assembles one batch
+        # while the card works on the other
+        K = 32
+        W = np.ascontiguousarray(np.broadcast_to(np.asarray(wit), (K,) + np.asarray(wit).shape))
+        R = np.ascontiguousarray(np.broadcast_to(r, (K, 4))); S = np.ascontiguousarray(np.broadcast_to(s_, (K, 4)))
+        ring, total, same_b = ctxb[:2], 8, True
+        t0 = time.perf_counter()
+        for i in range(total + 2):
+            c = ring[i % 2]
+            if i >= 2:
+                same_b = same_b and all(p == single[3] for p in v.groth16_prove_batch_finish(c)[3])
+            if i < total:
+                v.groth16_prove_batch_launch(c, dcs, kpp.pk, W, R, S)
+        multi["one_thread_two_batches_of_32_in_flight"] = total * K / (time.perf_counter() - t0)
+        multi["one_thread_every_proof_equals_the_single_call"] = bool(same_b)
         for c in ctxb[1:]:
             c.close()
         out[f"prove_2p{log_m}_batched_multi_context_proofs_per_s"] = multi

@@ -272,6 +272,12 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
  * window multiples, which buy a single proof ~5 %); VSP_ERR_UNSUPPORTED otherwise.  No SAVER addend (vsp_saver_encrypt proves one vote). */
 int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count,
                             const uint64_t *r, const uint64_t *s, uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out);
+/* The batch in two halves, as vsp_groth16_prove_launch / _finish below: launch copies the witnesses, r and s, queues every kernel of the
+ * `count` proofs and returns; finish does the host-side scalar multiplications, waits and assembles.  One host thread with two contexts
+ * over one key keeps the card busy while it assembles the other context's batch.  One batch (or one proof) in flight per context. */
+int vsp_groth16_prove_batch_launch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count,
+                                   const uint64_t *r, const uint64_t *s);
+int vsp_groth16_prove_batch_finish(vsp_ctx *ctx, uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out);
 /* The same proof in two halves, so that ONE host thread keeps several proofs in flight over one resident key -- one per context:
  *     vsp_groth16_prove_launch(ctxA, ...); vsp_groth16_prove_launch(ctxB, ...); vsp_groth16_prove_finish(ctxA, ...); launch(ctxA, next) ...
  * launch queues every kernel of the proof on the context's streams and returns (it copies r, s and the SAVER term; a witness in

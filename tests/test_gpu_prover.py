@@ -293,3 +293,39 @@ def test_batch_of_proofs_over_different_witnesses(ctx, cref):
         eA, eB, eC = kp.prove(wits[k], rs[k], ss[k])
         assert np.array_equal(A[k], eA) and np.array_equal(B[k], eB) and np.array_equal(Cc[k], eC), k
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_two_batches_in_flight_from_one_thread_over_two_contexts(ctx, cref):
+    """vsp_groth16_prove_batch_launch / _finish (round 4): one host thread keeps a batch in flight on each of two contexts over one plain key;
+    every proof of either batch is byte-identical to the blocking batch call; a second launch, a single-proof launch or a finish without a
+    launch on a busy / idle context is refused and leaves the batch in flight intact."""
+    nc, ni, K = 900, 4, 3
+    cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=41)
+    gen = o.splitmix64(4141)
+    def rand_batch():
+        return (np.ascontiguousarray(np.broadcast_to(wit0, (K,) + wit0.shape)), np.stack([L(o.rand_fr(gen), 4) for _ in range(K)]),
+                np.stack([L(o.rand_fr(gen), 4) for _ in range(K)]))
+    batches = [rand_batch() for _ in range(4)]
+    expect = [v.groth16_prove_batch(ctx, dcs, pk, *b)[3] for b in batches]
+    with v.Context(0) as c1:
+        with pytest.raises(v.VspError):
+            ctx.check(ctx.lib.vsp_groth16_prove_batch_finish(ctx.h, None, None, None, None))        # nothing in flight
+        with pytest.raises(RuntimeError):
+            v.groth16_prove_batch_finish(ctx)
+        ring = [ctx, c1]
+        got = [None] * 4
+        v.groth16_prove_batch_launch(ring[0], dcs, pk, *batches[0])
+        v.groth16_prove_batch_launch(ring[1], dcs, pk, *batches[1])
+        with pytest.raises(v.VspError):
+            ctx.check(ctx.lib.vsp_groth16_prove_batch_launch(ctx.h, dcs.h, pk.h, v.api._ptr(batches[2][0]), K, v.api._ptr(batches[2][1]), v.api._ptr(batches[2][2])))
+        with pytest.raises(v.VspError):
+            v.groth16_prove_launch(ctx, dcs, pk, wit0, r0, s0)                                        # a single proof on a context with a batch in flight
+        got[0] = v.groth16_prove_batch_finish(ring[0])[3]
+        v.groth16_prove_batch_launch(ring[0], dcs, pk, *batches[2])
+        got[1] = v.groth16_prove_batch_finish(ring[1])[3]
+        v.groth16_prove_batch_launch(ring[1], dcs, pk, *batches[3])
+        got[2] = v.groth16_prove_batch_finish(ring[0])[3]
+        got[3] = v.groth16_prove_batch_finish(ring[1])[3]
+        assert got == expect
+        assert v.groth16_prove(c1, dcs, pk, wit0, batches[0][1][0], batches[0][2][0])[3] == expect[0][0]
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

@@ -27,4 +27,15 @@ for K in (8, 16, 32):
         for x in th: x.start()
         for x in th: x.join()
         out.append("K=%d x %d contexts: %.0f/s" % (K, C, C * reps * K / (time.perf_counter() - t0)))
+    # ONE host thread, a batch in flight on each of C contexts (vsp_groth16_prove_batch_launch / _finish)
+    for C in (2, 3):
+        ring = ctxs[:C]
+        total = C * reps
+        t0 = time.perf_counter()
+        for i in range(total):
+            c = ring[i % C]
+            if i >= C: v.groth16_prove_batch_finish(c)
+            v.groth16_prove_batch_launch(c, dcs, kp.pk, W, R, S)
+        for i in range(total, total + C): v.groth16_prove_batch_finish(ring[i % C])
+        out.append("K=%d one thread x %d in flight: %.0f/s" % (K, C, total * K / (time.perf_counter() - t0)))
 print("2^%d: " % lg + "; ".join(out))

@@ -77,6 +77,8 @@ PROTOTYPES = {
     "vsp_pk_free": (None, [_P, _P]),
     "vsp_groth16_prove": (_I, [_P] * 12),
     "vsp_groth16_prove_batch": (_I, [_P, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
+    "vsp_groth16_prove_batch_launch": (_I, [_P, _P, _P, _P, _SZ, _P, _P]),
+    "vsp_groth16_prove_batch_finish": (_I, [_P, _P, _P, _P, _P]),
     "vsp_groth16_prove_launch": (_I, [_P] * 8),
     "vsp_groth16_prove_finish": (_I, [_P] * 5),
     "vsp_witness_pack_words": (_SZ, [_SZ]),

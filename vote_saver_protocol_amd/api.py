@@ -487,6 +487,30 @@ def groth16_prove_batch(ctx, cs, pk, witnesses, r, s):
     return A, B, Cc, [proofs[k].tobytes() for k in range(K)]
 
 
+def groth16_prove_batch_launch(ctx, cs, pk, witnesses, r, s):
+    """first half of groth16_prove_batch: copy the witnesses, queue every kernel of the K proofs, return K (one batch in flight per context)"""
+    witnesses = np.ascontiguousarray(witnesses, dtype=np.uint64)
+    if witnesses.ndim != 3 or witnesses.shape[1:] != (cs.num_vars, 4):
+        raise ValueError("prove_batch: witnesses must be [K, num_vars, 4]")
+    K = witnesses.shape[0]
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(K, 4); s = np.ascontiguousarray(s, dtype=np.uint64).reshape(K, 4)
+    ctx.check(ctx.lib.vsp_groth16_prove_batch_launch(ctx.h, cs.h, pk.h, _ptr(witnesses), K, _ptr(r), _ptr(s)))
+    ctx._prove_batch_count = K
+    return K
+
+
+def groth16_prove_batch_finish(ctx):
+    """second half: -> (A [K, 12], B [K, 24], C [K, 12], [proof bytes] * K) of the batch of K launched on this context"""
+    K = getattr(ctx, "_prove_batch_count", 0)
+    if not K:
+        raise RuntimeError("prove_batch_finish: no batch in flight on this context")
+    ctx._prove_batch_count = 0
+    A = np.zeros((K, 12), np.uint64); B = np.zeros((K, 24), np.uint64); Cc = np.zeros((K, 12), np.uint64)
+    proofs = np.zeros((K, 192), np.uint8)
+    ctx.check(ctx.lib.vsp_groth16_prove_batch_finish(ctx.h, _ptr(A), _ptr(B), _ptr(Cc), _ptr(proofs)))
+    return A, B, Cc, [proofs[k].tobytes() for k in range(K)]
+
+
 class PackedWitness:
     """the witness in the packed form of vsp_witness_pack: two class bits per wire, per-word offsets, the dense values"""
 

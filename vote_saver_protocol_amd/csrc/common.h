@@ -128,6 +128,8 @@ struct vsp_ctx {
     vsp::DevBuf pr_bz, pr_babc, pr_bh;      // vsp_groth16_prove_batch: [K][num_vars + 1], [K][3][m], [K][m]
     // a proof in flight between vsp_groth16_prove_launch and _finish (one per context)
     struct { bool active = false; const vsp_pk *pk = nullptr; uint64_t r[4], s[4], P1[12], r_enc[4]; bool has_saver = false; } prove;
+    // a BATCH of proofs in flight between vsp_groth16_prove_batch_launch and _finish (one per context)
+    struct { bool active = false; const vsp_pk *pk = nullptr; size_t count = 0; std::vector<uint64_t> r, s; } prove_batch;
 };
 
 struct vsp_bases {

@@ -156,7 +156,7 @@ static int prove_launch_checked(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *
                                 const uint64_t *saver_P1, const uint64_t *saver_r_enc) {
     if (!ctx) return VSP_ERR_ARG;
     if (!cs || !pk || !r || !s || (!w.plain && !(w.class_words && w.word_offsets && (w.dense || !w.n_dense)))) return set_error(ctx, VSP_ERR_ARG, "prove: null argument");
-    if (ctx->prove.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
+    if (ctx->prove.active || ctx->prove_batch.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
     if (!fr_canonical(r) || !fr_canonical(s) || (saver_r_enc && !fr_canonical(saver_r_enc)))
         return set_error(ctx, VSP_ERR_ARG, "prove: r, s and r_enc must be canonical (< r)");
     int rc = prove_launch_impl(ctx, cs, pk, w, r, s, saver_P1, saver_r_enc);
@@ -457,8 +457,7 @@ static void prove_batch_cleanup(vsp_ctx *ctx, int rc) {
     for (unsigned k = 1; k <= 4; k++) (void)msm_slot_use_stream(ctx, k, nullptr);
     if (ctx->pr_bz.p) hipMemsetAsync(ctx->pr_bz.p, 0, ctx->pr_bz.cap, ctx->stream);      // the witnesses do not outlive the call in device memory
 }
-static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t K, const uint64_t *r, const uint64_t *s,
-                            uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+static int prove_batch_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t K) {
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints, m = cs->dom.m, zs = nv + 1;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
         return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
@@ -496,6 +495,14 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
     VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false));
     VSP_TRY(launch_on_bases_batch(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, (unsigned)K, zs, false));
     lap("prove_batch_launch_ms");
+    return VSP_OK;
+}
+static int prove_batch_finish_impl(vsp_ctx *ctx, const vsp_pk *pk, size_t K, const uint64_t *r, const uint64_t *s,
+                                   uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *name) { double t = now(); ctx->stats[name] += t - t_prev; t_prev = t; };
+    VSP_HIP(hipSetDevice(ctx->device));
     // host work that needs no result: the delta multiples of every proof
     XYZZ<HFp> dj = xyzz_from_affine(pk->delta_g1);
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
@@ -545,16 +552,34 @@ static int prove_batch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, 
     ctx->stats["prove_batches"] += 1;
     return VSP_OK;
 }
-int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count, const uint64_t *r, const uint64_t *s,
-                            uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+static int prove_batch_launch_checked(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count, const uint64_t *r, const uint64_t *s) {
     if (!ctx) return VSP_ERR_ARG;
     if (!cs || !pk || !witnesses || !r || !s || count < 1 || count > 64) return set_error(ctx, VSP_ERR_ARG, "prove_batch: null argument or a batch outside 1..64");
-    if (ctx->prove.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
+    if (ctx->prove.active || ctx->prove_batch.active) return set_error(ctx, VSP_ERR_ARG, "prove: a proof is already in flight on this context (finish it first)");
     for (size_t k = 0; k < count; k++)
         if (!fr_canonical(r + 4 * k) || !fr_canonical(s + 4 * k)) return set_error(ctx, VSP_ERR_ARG, "prove: r and s must be canonical (< r)");
-    int rc = prove_batch_impl(ctx, cs, pk, witnesses, count, r, s, A_out, B_out, C_out, proofs_out);
+    int rc = prove_batch_launch_impl(ctx, cs, pk, witnesses, count);
+    if (rc != VSP_OK) { prove_batch_cleanup(ctx, rc); return rc; }
+    ctx->prove_batch.active = true; ctx->prove_batch.pk = pk; ctx->prove_batch.count = count;
+    ctx->prove_batch.r.assign(r, r + 4 * count); ctx->prove_batch.s.assign(s, s + 4 * count);
+    return VSP_OK;
+}
+int vsp_groth16_prove_batch_launch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count, const uint64_t *r, const uint64_t *s) {
+    return prove_batch_launch_checked(ctx, cs, pk, witnesses, count, r, s);
+}
+int vsp_groth16_prove_batch_finish(vsp_ctx *ctx, uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+    if (!ctx) return VSP_ERR_ARG;
+    if (!ctx->prove_batch.active) return set_error(ctx, VSP_ERR_ARG, "prove_batch_finish: no batch in flight on this context");
+    int rc = prove_batch_finish_impl(ctx, ctx->prove_batch.pk, ctx->prove_batch.count, ctx->prove_batch.r.data(), ctx->prove_batch.s.data(), A_out, B_out, C_out, proofs_out);
+    ctx->prove_batch.active = false;
     prove_batch_cleanup(ctx, rc);
     return rc;
+}
+int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count, const uint64_t *r, const uint64_t *s,
+                            uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out) {
+    int rc = prove_batch_launch_checked(ctx, cs, pk, witnesses, count, r, s);
+    if (rc != VSP_OK) return rc;
+    return vsp_groth16_prove_batch_finish(ctx, A_out, B_out, C_out, proofs_out);
 }
 
 }  // extern "C"
