@@ -12,6 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = v.Context(0)
+ctx2 = v.Context(0)
 t0 = time.time(); it = 0; kinds = {"basic_radix2": 0, "step_radix2": 0}
 last = time.time()
 while time.time() - t0 < budget:
@@ -40,7 +41,16 @@ while time.time() - t0 < budget:
     if ok and not pre and rng.random() < 0.6:                 # the same statement(s) through the batch prover (plain keys; basic and step domains)
         K = int(rng.integers(1, 7))
         R = rand_fr_array(K, seed=s + 4); S = rand_fr_array(K, seed=s + 5)
-        bA, bB, bC, _ = v.groth16_prove_batch(ctx, dcs, kp.pk, np.stack([wit] * K), R, S)
+        if rng.random() < 0.5:
+            bA, bB, bC, _ = v.groth16_prove_batch(ctx, dcs, kp.pk, np.stack([wit] * K), R, S)
+        else:                                                 # the two halves, a second batch in flight on a second context meanwhile
+            v.groth16_prove_batch_launch(ctx, dcs, kp.pk, np.stack([wit] * K), R, S)
+            v.groth16_prove_batch_launch(ctx2, dcs, kp.pk, np.stack([wit] * K), S, R)
+            bA, bB, bC, _ = v.groth16_prove_batch_finish(ctx)
+            cA, cB, cC, _ = v.groth16_prove_batch_finish(ctx2)
+            xa, xb, xc = ref.prove(wit, S[K - 1], R[K - 1])
+            ok = ok and np.array_equal(cA[K - 1], xa) and np.array_equal(cB[K - 1], xb) and np.array_equal(cC[K - 1], xc)
+            kinds["two_halves"] = kinds.get("two_halves", 0) + 1
         for k in range(K):
             xa, xb, xc = ref.prove(wit, R[k], S[k])
             ok = ok and np.array_equal(bA[k], xa) and np.array_equal(bB[k], xb) and np.array_equal(bC[k], xc)
