@@ -329,3 +329,28 @@ def test_two_batches_in_flight_from_one_thread_over_two_contexts(ctx, cref):
         assert got == expect
         assert v.groth16_prove(c1, dcs, pk, wit0, batches[0][1][0], batches[0][2][0])[3] == expect[0][0]
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_contexts_that_proved_batches_return_their_device_memory(ctx, cref):
+    """vsp_destroy frees the batch prover's buffers too (witnesses, the 3 K evaluation vectors, the K coefficient vectors), also after a
+    batch that was launched and never finished: free device memory after the third create / prove / destroy cycle is what it was after the first"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+    nc, ni, K = 16000, 4, 16                                     # ~50 MB of batch buffers per context
+    cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=5)
+    W = np.ascontiguousarray(np.broadcast_to(wit0, (K,) + wit0.shape)); R = np.stack([r0] * K); S = np.stack([s0] * K)
+    expect = v.groth16_prove_batch(ctx, dcs, pk, W, R, S)[3]
+    seen = []
+    for cycle in range(3):
+        c1 = v.Context(0)
+        assert v.groth16_prove_batch(c1, dcs, pk, W, R, S)[3] == expect
+        v.groth16_prove_batch_launch(c1, dcs, pk, W, R, S)       # left in flight: destroy waits it out
+        c1.close()
+        seen.append(free_bytes())
+    assert abs(seen[2] - seen[0]) < (8 << 20), seen
+    assert v.groth16_prove_batch(ctx, dcs, pk, W, R, S)[3] == expect
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

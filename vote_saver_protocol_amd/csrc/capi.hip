@@ -185,11 +185,12 @@ vsp_ctx *vsp_create(int device_ordinal) {
 void vsp_destroy(vsp_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->prove.active || ctx->prove_batch.active) msm_drain_slots(ctx);      // a proof launched and never finished: wait its kernels out before their buffers go
     hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->ntt.fwd, &ctx->ntt.inv, &ctx->ntt.pw_lo_f, &ctx->ntt.pw_hi_f, &ctx->ntt.pw_lo_i, &ctx->ntt.pw_hi_i, &ctx->ntt_scratch, &ctx->dom_scratch,
                       &ctx->ntt.fwd29, &ctx->ntt.inv29, &ctx->ntt.pw29[0], &ctx->ntt.pw29[1], &ctx->ntt.pw29[2], &ctx->ntt.pw29[3],
                       &ctx->msm_scalars, &ctx->val_flag, &ctx->fb_g1, &ctx->fb_g2, &ctx->fb_tmp, &ctx->fb_pre,
-                      &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h, &ctx->pr_pack};
+                      &ctx->pr_z, &ctx->pr_a, &ctx->pr_b, &ctx->pr_c, &ctx->pr_h, &ctx->pr_pack, &ctx->pr_bz, &ctx->pr_babc, &ctx->pr_bh};
     for (DevBuf *b : bufs) free_buf(*b);
     msm_free_slots(ctx);
     if (ctx->h_fold) hipHostFree(ctx->h_fold);
