@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "build", "libvsp_ref.so")
+_SO = os.environ.get("VSP_REF_SO") or os.path.join(_HERE, "build", "libvsp_ref.so")      # VSP_REF_SO: another build of vsp_ref.c (the sanitizer run of tests/test_oracle.py)
 
 
 def build():

@@ -15,7 +15,8 @@ from conftest import I, L, ROOT, dec1, dec2, g1_limbs, g2_limbs, load_golden
 @pytest.fixture(scope="module")
 def mc(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("cpu_build") / "libmathchk.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+    flags = os.environ.get("VSP_MATHCHK_FLAGS", "-O2").split()      # tests/test_sanitizers_cpu.py re-runs this file with sanitizer flags
+    subprocess.check_call(["g++"] + flags + ["-std=c++17", "-shared", "-fPIC", "-o", so,
                            os.path.join(ROOT, "tests", "cpu_build", "math_check.cpp")])
     return C.CDLL(so)
 
