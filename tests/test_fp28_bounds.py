@@ -237,8 +237,8 @@ def add28(a, b):
 def mulF2(a, b, KB):
     a0, a1 = a; b0, b1 = b
     even = mm28(a0, b0, a1, neg28(KB, b1))          # a0 b0 + a1 (K - b1)
-    # fp28.h mulF2, odd lane: u = ap = a0, b = b1 (own), w = a = a1, nb = bp = b0  ->  a0 b1 + a1 b0
-    odd = mm28(a0, b1, a1, b0)
+    # fp28.h mulF2, odd lane: own a = a1 times the partner's b = b0, the partner's a = a0 times own b = b1  ->  a1 b0 + a0 b1
+    odd = mm28(a1, b0, a0, b1)
     return even, odd
 
 

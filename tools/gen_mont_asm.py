@@ -280,6 +280,8 @@ __device__ __forceinline__ void mont_mul28x2_asm(uint32_t *r, const uint32_t *a,
 # ---------------------------------------------------------------- carry-free 9 x 29-bit product for Fr (R' = 2^261): the NTT butterflies
 R255 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 N29, W29 = 9, 29
+A29, B29, M29, T29, ACC29 = 64, 74, 84, 73, 94   #                     # first register of operand b and of the result in vsp_mm29's register map
+QA29, QM29, QT29, QACC29 = 96, 108, 105, 106   #     # vsp_mm29q: a v32..40, b v10..18 (shared with vsp_mm29), result v44..52, temp v41, accumulator v[42:43]
 MASK29 = (1 << W29) - 1
 
 
@@ -287,19 +289,22 @@ def limbs29(v):
     return [(v >> (W29 * i)) & MASK29 for i in range(N29 - 1)] + [v >> (W29 * (N29 - 1))]
 
 
-def body29():
+def body29(a0=A29, b0=B29, m0=M29, tmpreg=T29, acc=ACC29):
     """The 28-bit scheme for Fr: a column is 9 + 9 products below 2^60 (operand limb bounds 2^Ea, 2^Eb with Ea + Eb <= 60: a twiddle is
     tight, 29 bits, so a data operand may have limbs up to 2^31), one 64-bit accumulator, no carries.  r = 1 mod 2^32, so -1/r = -1
     mod 2^29 and m_k is a negation and a mask instead of a multiplication.  Output: limbs below 2^29 (top limb the rest), value below
-    a*b / 2^261 + r; a and b are preserved.  Register map: a v0..8, b v9..17, m / result v18..26, temp v27, accumulator v[28:29];
-    s0..s8 = r's limbs, s9 = mask."""
-    A = lambda i: f"v{i}"
-    B = lambda i: f"v{N29 + i}"
-    M = lambda i: f"v{2 * N29 + i}"
+    a*b / 2^261 + r; a and b are preserved.  Register map: a v0..8, b v10..18, m / result v20..28, temp v9, accumulator v[30:31]
+    (v19, v29 unused); s0..s8 = r's limbs, s9 = mask.  Every operand starts at a multiple of FOUR: the three planes of a value (two 128-bit
+    words and a dword) are loaded from LDS / memory straight into v[0:3] v[4:7] v8, v[10:13] v[14:17] v18 and stored from v[20:23] v[24:27]
+    v28 -- register tuples of 64 bits and more start at even registers on gfx950, so round 3's b at v9..17 forced nine copies per twiddle."""
+    A = lambda i: f"v{a0 + i}"
+    B = lambda i: f"v{b0 + i}"
+    M = lambda i: f"v{m0 + i}"
     Pm = lambda i: f"s{i}"
     MSK = "s9"
-    base = 3 * N29 + 1                    # 64-bit register pairs must start at an even register on gfx950: v[28:29]; temp v27
-    lo, hi, pr, tmp = f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]", f"v{base - 1}"
+    base = acc                            # 64-bit register pairs must start at an even register on gfx950
+    assert base % 2 == 0 and a0 % 4 == 0 and m0 % 4 == 0 and b0 % 2 == 0
+    lo, hi, pr, tmp = f"v{base}", f"v{base + 1}", f"v[{base}:{base + 1}]", f"v{tmpreg}"
     ins = [f"v_mov_b32 {lo}, 0", f"v_mov_b32 {hi}, 0"]
     for k in range(2 * N29 - 1):
         for i in range(max(0, k - N29 + 1), min(k, N29 - 1) + 1):
@@ -328,20 +333,26 @@ def gen29():
     r29 = limbs29(R255)
     assert (-pow(R255, -1, 1 << W29)) % (1 << W29) == MASK29
     ins = body29()
+    insq = body29(QA29, B29, QM29, QT29, QACC29)
+    consts_s = [f's_mov_b32 s{i}, 0x{r29[i]:x}' for i in range(N29)] + [f's_mov_b32 s9, 0x{MASK29:x}']
     lines = ['s_branch .Lvsp_mm29_end', '.p2align 8', 'vsp_mm29:']
-    lines += [f's_mov_b32 s{i}, 0x{r29[i]:x}' for i in range(N29)] + [f's_mov_b32 s9, 0x{MASK29:x}']
-    lines += ins + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm29_end:']
+    lines += consts_s + ins + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm29_end:']
+    linesq = ['s_branch .Lvsp_mm29q_end', '.p2align 8', 'vsp_mm29q:'] + consts_s + insq + ['s_nop 4', 's_setpc_b64 s[30:31]', '.Lvsp_mm29q_end:']
     body_txt = "\n".join(f'        "{x}\\n\\t"' for x in lines)
-    vclob = ", ".join(f'"v{i}"' for i in range(3 * N29 + 3))
+    bodyq_txt = "\n".join(f'        "{x}\\n\\t"' for x in linesq)
+    vclob = ", ".join(f'"v{i}"' for i in range(A29, ACC29 + 2))
+    vclobq = ", ".join([f'"v{i}"' for i in range(B29, B29 + N29)] + [f'"v{i}"' for i in range(QA29, QM29 + N29)])
     sclob = ", ".join(f'"s{i}"' for i in range(10))
     n_mad = sum(1 for x in ins if x.startswith("v_mad"))
     arr = lambda name, v: f"static constexpr uint32_t {name}[9] = {{" + ", ".join(f"0x{x:x}u" for x in v) + "};"
     R1 = (1 << 261) % R255
     consts = "\n".join([arr("FR29_R", r29), arr("FR29_ONE", limbs29(R1)), arr("FR29_R2", limbs29(R1 * R1 % R255)),
                         arr("FR29_K2_L1", redundant29(2, 1)), arr("FR29_K4_L1", redundant29(4, 1))])
-    outs = ", ".join(f'"={{v{2 * N29 + i}}}"(r[{i}])' for i in range(N29))
-    inps = ", ".join([f'"{{v{i}}}"(a[{i}])' for i in range(N29)] + [f'"{{v{N29 + i}}}"(b[{i}])' for i in range(N29)])
-    return f"""// ---- Fr on 9 x 29-bit limbs, R' = 2^261: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v29 ----
+    outs = ", ".join(f'"={{v{M29 + i}}}"(r[{i}])' for i in range(N29))
+    inps = ", ".join([f'"{{v{A29 + i}}}"(a[{i}])' for i in range(N29)] + [f'"{{v{B29 + i}}}"(b[{i}])' for i in range(N29)])
+    outsq = ", ".join(f'"={{v{QM29 + i}}}"(r[{i}])' for i in range(N29))
+    inpsq = ", ".join([f'"{{v{QA29 + i}}}"(a[{i}])' for i in range(N29)] + [f'"{{v{B29 + i}}}"(b[{i}])' for i in range(N29)])
+    return f"""// ---- Fr on 9 x 29-bit limbs, R' = 2^261: {n_mad} v_mad_u64_u32, {len(ins)} instructions, no carries, no final subtraction; VGPRs v0..v31 ----
 // constants: r; R' mod r (the Montgomery one); R'^2 mod r; 2r and 4r in the redundant form of the lazy subtractions
 {consts}
 template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul29_holder() {{
@@ -359,7 +370,25 @@ __device__ __forceinline__ void mont_mul29_asm(uint32_t *r, const uint32_t *a, c
         "s_swappc_b64 s[30:31], s[30:31]"
         : {outs}
         : {inps}
-        : "vcc", "scc", "s30", "s31", {sclob}, "v27", "v28", "v29");
+        : "vcc", "scc", "s30", "s31", {sclob}, "v{T29}", "v{ACC29}", "v{ACC29 + 1}");
+}}
+template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul29q_holder() {{
+    asm volatile(
+{bodyq_txt}
+        :
+        :
+        : "vcc", "scc", "s30", "s31", {sclob}, {vclobq});
+}}
+// the same product with ANOTHER register map (a v32..40, the SAME b v10..18, result v44..52): the second product of a pair keeps its
+// operand and its result in registers of its own, so the pair x1 w, x3 w of a radix-4 step needs no copies in or out
+__device__ __forceinline__ void mont_mul29q_asm(uint32_t *r, const uint32_t *a, const uint32_t *b) {{
+    asm("s_getpc_b64 s[30:31]\\n\\t"
+        "s_add_u32 s30, s30, vsp_mm29q@rel32@lo+4\\n\\t"
+        "s_addc_u32 s31, s31, vsp_mm29q@rel32@hi+12\\n\\t"
+        "s_swappc_b64 s[30:31], s[30:31]"
+        : {outsq}
+        : {inpsq}
+        : "vcc", "scc", "s30", "s31", {sclob}, "v{QT29}", "v{QACC29}", "v{QACC29 + 1}");
 }}
 """
 

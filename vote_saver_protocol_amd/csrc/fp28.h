@@ -314,9 +314,11 @@ __device__ __forceinline__ Fp28 select28(bool c, const Fp28 &a, const Fp28 &b) {
 __device__ __forceinline__ Fp28 mulF2(const Fp28 &a, const Fp28 &b, const uint32_t (&KB)[14]) {
     const bool hi = (threadIdx.x & 1) != 0;
     Fp28 ap = partner28(a), bp = partner28(b);
-    Fp28 u = select28(hi, ap, a), w = select28(hi, a, ap);
-    Fp28 nb = select28(hi, bp, neg28(KB, bp));
-    return mul28x2(u, b, w, nb);                 // even: a0 b0 + a1 (K - b1)     odd: a0 b1 + a1 b0
+    // own a times (own b | partner's b), partner's a times (K - partner's b | own b): the a side needs no selection at all (round 3 selected
+    // both sides: 14 more v_cndmask per product)
+    Fp28 s1 = select28(hi, bp, b);
+    Fp28 s2 = select28(hi, b, neg28(KB, bp));
+    return mul28x2(a, s1, ap, s2);               // even: a0 b0 + a1 (K - b1)     odd: a1 b0 + a0 b1
 }
 // KA dominates the partner component of a
 __device__ __forceinline__ Fp28 sqrF2(const Fp28 &a, const uint32_t (&KA)[14]) {

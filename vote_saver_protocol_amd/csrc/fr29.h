@@ -75,6 +75,7 @@ __device__ __noinline__ void mont29_portable(uint32_t *r, const uint32_t *a, con
     r[8] = (uint32_t)acc;
 }
 __device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) { Fr29 r; mont29_portable(r.l, a.l, b.l); return r; }
+__device__ __forceinline__ Fr29 mul29q(const Fr29 &a, const Fr29 &b) { return mul29(a, b); }
 #else
 __device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) {
     Fr29 r;
@@ -82,6 +83,16 @@ __device__ __forceinline__ Fr29 mul29(const Fr29 &a, const Fr29 &b) {
     mont_mul29_asm(r.l, a.l, b.l);
     __builtin_amdgcn_sched_barrier(0);
     (void)&mont_mul29_holder<0>;
+    return r;
+}
+// the same product through the routine's second register map (vsp_mm29q: operand and result in registers of their own, b shared): the
+// second product of a pair, so that neither its operand nor the first product's result has to be copied around the call
+__device__ __forceinline__ Fr29 mul29q(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+    __builtin_amdgcn_sched_barrier(0);
+    mont_mul29q_asm(r.l, a.l, b.l);
+    __builtin_amdgcn_sched_barrier(0);
+    (void)&mont_mul29q_holder<0>;
     return r;
 }
 #endif

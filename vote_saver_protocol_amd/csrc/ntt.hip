@@ -26,6 +26,7 @@
 //  * The path is integer-ALU bound (one 8-limb Montgomery product per butterfly), not HBM bound.
 #include <algorithm>
 #include "common.h"
+#include <type_traits>
 #include "fr29.h"
 
 namespace vsp {
@@ -258,25 +259,32 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt29_pass(Planes29 in_lazy, Pl
     for (; t < K; t += 2) {
         const unsigned s = p.s0 + t;
         const unsigned h = 1u << t;
-        for (unsigned g = tid; g < (tile >> 2); g += NTT_THREADS) {
+        // the first pair of products exists from stage 1 on (stage 0's twiddle is one).  Two copies of the loop, not a branch inside it:
+        // a value that is "the loaded x1 or the product" is ONE register set for the compiler, which then loads x1 into the routine's
+        // result registers and copies it to the operand registers before every call (nine copies per product, section 3.2 of DESIGN.md)
+        auto group = [&](unsigned g, auto with_first_pair) {
+            constexpr bool TW1 = decltype(with_first_pair)::value;
             unsigned c = g & (C - 1), q = g >> p.clog;
             unsigned mid_lo = q & (h - 1);
             unsigned mid0 = ((q >> t) << (t + 2)) | mid_lo;
             unsigned e0 = (mid0 << p.clog) | c, e1 = e0 + (h << p.clog), e2 = e1 + (h << p.clog), e3 = e2 + (h << p.clog);
             const size_t off = p.first ? 0u : (lo_part | c);
-            Fr29 x0 = lds_load29(pl0, pl1, pl2, e0), x1 = lds_load29(pl0, pl1, pl2, e1), x2 = lds_load29(pl0, pl1, pl2, e2), x3 = lds_load29(pl0, pl1, pl2, e3);
-            if (s > 0) {
+            Fr29 x1 = lds_load29(pl0, pl1, pl2, e1), x3 = lds_load29(pl0, pl1, pl2, e3);
+            if constexpr (TW1) {
                 const Fr29 w1 = ld29(p.tw, (((size_t)mid_lo << p.s0) | off) << (p.tlog - 1 - s));
-                x1 = mul29(x1, w1); x3 = mul29(x3, w1);
+                x1 = mul29(x1, w1); x3 = mul29q(x3, w1);
             }
+            Fr29 x0 = lds_load29(pl0, pl1, pl2, e0), x2 = lds_load29(pl0, pl1, pl2, e2);
             Fr29 a0 = add29(x0, x1), a1 = sub29(x0, x1), a2 = add29(x2, x3), a3 = sub29(x2, x3);
             a2 = mul29(a2, ld29(p.tw, (((size_t)mid_lo << p.s0) | off) << (p.tlog - 2 - s)));
-            a3 = mul29(a3, ld29(p.tw, (((size_t)(mid_lo + h) << p.s0) | off) << (p.tlog - 2 - s)));
+            a3 = mul29q(a3, ld29(p.tw, (((size_t)(mid_lo + h) << p.s0) | off) << (p.tlog - 2 - s)));
             lds_store29(pl0, pl1, pl2, e0, norm29(add29(a0, a2)));
             lds_store29(pl0, pl1, pl2, e1, norm29(add29(a1, a3)));
             lds_store29(pl0, pl1, pl2, e2, norm29(sub29(a0, a2)));
             lds_store29(pl0, pl1, pl2, e3, norm29(sub29(a1, a3)));
-        }
+        };
+        if (s > 0) for (unsigned g = tid; g < (tile >> 2); g += NTT_THREADS) group(g, std::true_type{});
+        else for (unsigned g = tid; g < (tile >> 2); g += NTT_THREADS) group(g, std::false_type{});
         __syncthreads();
     }
 
