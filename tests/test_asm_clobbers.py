@@ -17,19 +17,21 @@ def test_every_register_a_routine_writes_is_declared_where_it_is_entered():
         assert any(("entered at " + label + ":") in x for x in lines), label
 
 
-def test_no_read_of_a_clobbered_register_after_a_routine_entry_in_the_generated_isa(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("unit,min_functions", [("msm_g1.hip", 20), ("ntt.hip", 3)])
+def test_no_read_of_a_clobbered_register_after_a_routine_entry_in_the_generated_isa(tmp_path, unit, min_functions):
     """the other side of the interface (round 4, tools/check_call_sites.py): in the ISA the compiler generates for the 28-bit MSM kernels
-    (msm_g1.hip, shipped flags), no instruction reads a register that a routine entry before it clobbered and nothing has rewritten --
-    linear scan between labels, 30+ kernels with routine entries"""
-    import shutil
+    (msm_g1.hip, shipped flags) and for the transforms (ntt.hip: vsp_mm29 and vsp_mm29q, two register maps), no instruction reads a register
+    that a routine entry before it clobbered and nothing has rewritten -- linear scan between labels"""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        import pytest
         pytest.skip("hipcc not installed")
-    out = str(tmp_path / "msm_g1.s")
+    out = str(tmp_path / (unit + ".s"))
     csrc = os.path.join(ROOT, "vote_saver_protocol_amd", "csrc")
     subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-unused-value",
-                           "-Wno-unused-result", "-mllvm", "-enable-misched=0", "--cuda-device-only", "-S", "msm_g1.hip", "-o", out], cwd=csrc, stderr=subprocess.DEVNULL)
+                           "-Wno-unused-result", "-mllvm", "-enable-misched=0", "--cuda-device-only", "-S", unit, "-o", out], cwd=csrc, stderr=subprocess.DEVNULL)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_call_sites.py"), out], capture_output=True, text=True)
     assert r.returncode == 0 and "0 suspicious read(s)" in r.stdout, r.stdout[-2000:]
-    assert int(r.stdout.split("check_call_sites: ")[1].split(" ")[0]) >= 20
+    assert int(r.stdout.split("check_call_sites: ")[1].split(" ")[0]) >= min_functions
