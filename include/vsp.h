@@ -80,7 +80,9 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * "prove_host_threads" (default 1: the prover's host steps -- the four multiples of delta, the Horner chain over each multi-exponentiation's
  * window results, s*A and r*B1 -- run on host threads of their own inside the wait for the GPU; 0: on the calling thread, one after the other),
  * "witness_map_batched" (default 1: the three transforms of every step of witness_map in one launch per pass and the pointwise step inside
- * the last transform's first pass, basic domains on the 29-bit butterflies; 0: transform by transform), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library), "msm_dimbits" (1 / 0: the last
+ * the last transform's first pass, basic domains on the 29-bit butterflies; 0: transform by transform), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library),
+ * "msm_dimsum_maxw" (256..4096, default 1024: waves the per-digit lane plan of the bucket reduction may fill; 2048 = two per SIMD),
+ * "msm_dimsum_prefetch" (1: the bucket reduction requests the next bucket before the current addition; default 0, it spills), "msm_dimbits" (1 / 0: the last
  * step of the bucket reduction as plain subset sums folded by the host's doubling chain / as weighted sums on the GPU; default by group),
  * "msm_slot_normal_priority" (1 before the first use of a work slot: its stream gets the context's priority instead of the lowest --
  * faster single proofs, slower independent multi-exponentiations in flight), "ntt_fr29" (default 1: butterflies on
