@@ -79,6 +79,8 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
  * "prove_host_threads" (default 1: the prover's host steps -- the four multiples of delta, the Horner chain over each multi-exponentiation's
  * window results, s*A and r*B1 -- run on host threads of their own inside the wait for the GPU; 0: on the calling thread, one after the other),
+ * "prove_batch_share_plan" (default 1: in vsp_groth16_prove_batch the B1 and B2 multi-exponentiations take A's digit sort and bucket plan --
+ * the three multiply by the same witness vectors; 0: each sorts for itself),
  * "witness_map_batched" (default 1: the three transforms of every step of witness_map in one launch per pass and the pointwise step inside
  * the last transform's first pass, basic domains on the 29-bit butterflies; 0: transform by transform), "msm_dimsum_lanes" (8/16/32/64 lanes per bucket-digit sum; 0 = chosen by the library),
  * "msm_dimsum_maxw" (256..4096, default 1024: waves the per-digit lane plan of the bucket reduction may fill; 2048 = two per SIMD),

@@ -354,3 +354,22 @@ def test_contexts_that_proved_batches_return_their_device_memory(ctx, cref):
     assert abs(seen[2] - seen[0]) < (8 << 20), seen
     assert v.groth16_prove_batch(ctx, dcs, pk, W, R, S)[3] == expect
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_batch_prover_with_and_without_the_shared_digit_sort(ctx, cref):
+    """A, B1 and B2 of a batch multiply by the same K witness vectors: by default B1 and B2 take A's digit sort and bucket plan (option
+    prove_batch_share_plan = 1); with 0 every multi-exponentiation sorts for itself.  Same proofs either way, equal to the single call's;
+    the last reduction step of a batch (k_dimbits since the end of round 4, msm_dimbits = 0: k_dimweight) does not change them either."""
+    nc, ni, K = 3000, 5, 6
+    cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=23)
+    gen = o.splitmix64(2323)
+    W = np.ascontiguousarray(np.broadcast_to(wit0, (K,) + wit0.shape))
+    R = np.stack([L(o.rand_fr(gen), 4) for _ in range(K)]); S = np.stack([L(o.rand_fr(gen), 4) for _ in range(K)])
+    singles = [v.groth16_prove(ctx, dcs, pk, wit0, R[k], S[k])[3] for k in range(K)]
+    try:
+        for share, dimbits in ((1, -1), (0, -1), (1, 0), (0, 0), (1, 1)):
+            ctx.set_option("prove_batch_share_plan", share); ctx.set_option("msm_dimbits", dimbits)
+            assert v.groth16_prove_batch(ctx, dcs, pk, W, R, S)[3] == singles, (share, dimbits)
+    finally:
+        ctx.set_option("prove_batch_share_plan", 1); ctx.set_option("msm_dimbits", -1)
+    pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()

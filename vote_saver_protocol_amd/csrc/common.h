@@ -252,9 +252,9 @@ int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr
                   const void *plain_table28 = nullptr, bool glv = false);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 // a batch of scalar vectors over one set of PLAIN bases (MsmGeom.K): vector k at d_scalars + k * stride; one result per vector
-int msm_g1_launch_batch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv);
+int msm_g1_launch_batch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1);
 int msm_g1_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out, unsigned batch);
-int msm_g2_launch_batch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv);
+int msm_g2_launch_batch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1);
 int msm_g2_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out, unsigned batch);
 // a finish in two halves: the wait (context state: caller's thread) and the fold of the window results (pure host arithmetic over the slot: any thread)
 int msm_g1_finish_wait(vsp_ctx *ctx, unsigned slot, bool *empty);
@@ -262,7 +262,7 @@ void msm_g1_fold(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out);
 int msm_g2_finish_wait(vsp_ctx *ctx, unsigned slot, bool *empty);
 void msm_g2_fold(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, int plan_from_slot);
-int launch_on_bases_batch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, unsigned batch, size_t stride, bool dense);
+int launch_on_bases_batch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, unsigned batch, size_t stride, bool dense, int plan_from_slot = -1);
 int msm_slot_stream(vsp_ctx *ctx, unsigned slot, hipStream_t *out);
 int msm_slot_census(vsp_ctx *ctx, unsigned slot, const Fr *d_scalars, size_t n);
 void msm_free_slots(vsp_ctx *ctx);

@@ -491,8 +491,12 @@ static int prove_batch_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_p
     VSP_TRY(witness_map_device_batch(ctx, abc, (unsigned)K, &cs->dom, dH));
     VSP_TRY(launch_on_bases_batch(ctx, 0, pk->H, 0, m - 1, dH, (unsigned)K, m, true));           // H coefficients are dense
     VSP_TRY(launch_on_bases_batch(ctx, 1, pk->A, 0, nv + 1, dz, (unsigned)K, zs, false));
-    VSP_TRY(launch_on_bases_batch(ctx, 3, pk->B2, 0, nv + 1, dz, (unsigned)K, zs, false));
-    VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false));
+    // A, B1 and B2 multiply by the same K witness vectors: one digit sort and bucket plan (A's) serves the three (option "prove_batch_share_plan")
+    long share = 1; { auto it = ctx->opts.find("prove_batch_share_plan"); if (it != ctx->opts.end()) share = it->second; }
+    const bool same_shape = pk->A->glv == pk->B1->glv && pk->A->glv == pk->B2->glv && (pk->A->d28 != nullptr) == (pk->B1->d28 != nullptr) && (pk->A->d28 != nullptr) == (pk->B2->d28 != nullptr);
+    const int from_a = share && same_shape && nv + 1 > 0 ? 1 : -1;
+    VSP_TRY(launch_on_bases_batch(ctx, 3, pk->B2, 0, nv + 1, dz, (unsigned)K, zs, false, from_a));
+    VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false, from_a));
     VSP_TRY(launch_on_bases_batch(ctx, 4, pk->L, 0, nv - ni, dz + ni + 1, (unsigned)K, zs, false));
     lap("prove_batch_launch_ms");
     return VSP_OK;
