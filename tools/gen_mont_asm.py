@@ -280,8 +280,13 @@ __device__ __forceinline__ void mont_mul28x2_asm(uint32_t *r, const uint32_t *a,
 # ---------------------------------------------------------------- carry-free 9 x 29-bit product for Fr (R' = 2^261): the NTT butterflies
 R255 = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 N29, W29 = 9, 29
-A29, B29, M29, T29, ACC29 = 64, 74, 84, 73, 94   #                     # first register of operand b and of the result in vsp_mm29's register map
-QA29, QM29, QT29, QACC29 = 96, 108, 105, 106   #     # vsp_mm29q: a v32..40, b v10..18 (shared with vsp_mm29), result v44..52, temp v41, accumulator v[42:43]
+# vsp_mm29:  a v64..72, b v74..82, result v84..92, temp v73, accumulator v[94:95]
+# vsp_mm29q: a v96..104, the SAME b v74..82, result v108..116, temp v105, accumulator v[106:107]
+# HIGH registers on purpose: the compiler hands out registers from v0 upwards for its own short-lived values (addresses, loop counters), and
+# fixed operand registers down there collide with them -- every collision is a copy before the call.  Up here the LDS and table loads of a
+# radix-4 group land straight in the operand registers (k_ntt29_pass: 126 VGPRs in all, four waves per SIMD).
+A29, B29, M29, T29, ACC29 = 64, 74, 84, 73, 94
+QA29, QM29, QT29, QACC29 = 96, 108, 105, 106
 MASK29 = (1 << W29) - 1
 
 
@@ -293,10 +298,11 @@ def body29(a0=A29, b0=B29, m0=M29, tmpreg=T29, acc=ACC29):
     """The 28-bit scheme for Fr: a column is 9 + 9 products below 2^60 (operand limb bounds 2^Ea, 2^Eb with Ea + Eb <= 60: a twiddle is
     tight, 29 bits, so a data operand may have limbs up to 2^31), one 64-bit accumulator, no carries.  r = 1 mod 2^32, so -1/r = -1
     mod 2^29 and m_k is a negation and a mask instead of a multiplication.  Output: limbs below 2^29 (top limb the rest), value below
-    a*b / 2^261 + r; a and b are preserved.  Register map: a v0..8, b v10..18, m / result v20..28, temp v9, accumulator v[30:31]
-    (v19, v29 unused); s0..s8 = r's limbs, s9 = mask.  Every operand starts at a multiple of FOUR: the three planes of a value (two 128-bit
-    words and a dword) are loaded from LDS / memory straight into v[0:3] v[4:7] v8, v[10:13] v[14:17] v18 and stored from v[20:23] v[24:27]
-    v28 -- register tuples of 64 bits and more start at even registers on gfx950, so round 3's b at v9..17 forced nine copies per twiddle."""
+    a*b / 2^261 + r; a and b are preserved.  Register map: the arguments (a0, b0, m0: first register of a, b and the result; a temporary; the
+    64-bit accumulator pair); s0..s8 = r's limbs, s9 = mask.  Every operand starts at an even register whose 4-register groups are even too:
+    the three planes of a value (two 128-bit words and a dword) are loaded from LDS / memory straight into the operand registers and stored
+    straight from the result registers -- register tuples of 64 bits and more start at even registers on gfx950, so round 3's b at v9..17
+    forced nine copies per twiddle."""
     A = lambda i: f"v{a0 + i}"
     B = lambda i: f"v{b0 + i}"
     M = lambda i: f"v{m0 + i}"
