@@ -385,7 +385,7 @@ template <int Instance> __device__ __attribute__((noinline, used)) void mont_mul
         :
         : "vcc", "scc", "s30", "s31", {sclob}, {vclobq});
 }}
-// the same product with ANOTHER register map (a v32..40, the SAME b v10..18, result v44..52): the second product of a pair keeps its
+// the same product with ANOTHER register map (a v{QA29}..{QA29 + 8}, the SAME b v{B29}..{B29 + 8}, result v{QM29}..{QM29 + 8}): the second product of a pair keeps its
 // operand and its result in registers of its own, so the pair x1 w, x3 w of a radix-4 step needs no copies in or out
 __device__ __forceinline__ void mont_mul29q_asm(uint32_t *r, const uint32_t *a, const uint32_t *b) {{
     asm("s_getpc_b64 s[30:31]\\n\\t"
