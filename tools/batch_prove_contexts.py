@@ -15,7 +15,7 @@ dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
 kp = v.Keypair(ctx, dcs, tox, precompute=0)
 ctxs = [ctx] + [v.Context(0) for _ in range(3)]
 out = []
-for K in (8, 16, 32):
+for K in [int(x) for x in os.environ.get("KS", "8,16,32").split(",")]:
     R = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(K)], np.uint64); S = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(K)], np.uint64)
     W = np.ascontiguousarray(np.broadcast_to(wit, (K,) + wit.shape))
     for c in ctxs: v.groth16_prove_batch(c, dcs, kp.pk, W, R, S)
