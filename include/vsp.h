@@ -79,6 +79,8 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
  * "prove_host_threads" (default 1: the prover's host steps -- the four multiples of delta, the Horner chain over each multi-exponentiation's
  * window results, s*A and r*B1 -- run on host threads of their own inside the wait for the GPU; 0: on the calling thread, one after the other),
+ * "prove_fixed_base" (default 1: the multiples of delta every proof needs come from fixed-base tables of 32 x 255 multiples per group,
+ * built on the host by the first proof over a key -- at most 32 additions per multiple; 0: double-and-add),
  * "prove_batch_share_plan" (default 1: in vsp_groth16_prove_batch the B1 and B2 multi-exponentiations take A's digit sort and bucket plan --
  * the three multiply by the same witness vectors; 0: each sorts for itself),
  * "witness_map_batched" (default 1: the three transforms of every step of witness_map in one launch per pass and the pointwise step inside

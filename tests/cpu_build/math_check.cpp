@@ -51,7 +51,22 @@ template <class F> static void curve_op(int op, const uint64_t *p, const uint64_
     r.x = from_mont(r.x); r.y = from_mont(r.y);
     store(out, r);
 }
+// k * p three ways (host types): mode 0 = bit by bit (xyzz_mul_scalar), 1 = 4-bit windows (xyzz_mul_scalar_w4), 2 = fixed-base table of 32 x 255
+// multiples (xyzz_fixed_base_table / xyzz_mul_fixed: the prover's multiples of delta)
+template <class F> static void scalar_mul(int mode, const uint64_t *p, const uint64_t *k, uint64_t *out) {
+    Affine<F> a = load<Affine<F>>(p);
+    a.x = to_mont(a.x); a.y = to_mont(a.y);
+    XYZZ<F> base = xyzz_from_affine(a), r;
+    if (mode == 0) r = xyzz_mul_scalar(base, k, 256);
+    else if (mode == 1) r = xyzz_mul_scalar_w4(base, k);
+    else { std::vector<XYZZ<F>> tab; xyzz_fixed_base_table(base, tab); r = xyzz_mul_fixed(tab, k); }
+    Affine<F> o = xyzz_to_affine(r);
+    o.x = from_mont(o.x); o.y = from_mont(o.y);
+    store(out, o);
+}
 extern "C" {
+void chk_hg1_mul(int mode, const uint64_t *p, const uint64_t *k, uint64_t *out) { scalar_mul<HFp>(mode, p, k, out); }
+void chk_hg2_mul(int mode, const uint64_t *p, const uint64_t *k, uint64_t *out) { scalar_mul<HFp2>(mode, p, k, out); }
 void chk_g1_op(int op, const uint64_t *p, const uint64_t *q, uint64_t *out) { curve_op<Fp>(op, p, q, out); }
 void chk_g2_op(int op, const uint64_t *p, const uint64_t *q, uint64_t *out) { curve_op<Fp2>(op, p, q, out); }
 void chk_hg1_op(int op, const uint64_t *p, const uint64_t *q, uint64_t *out) { curve_op<HFp>(op, p, q, out); }

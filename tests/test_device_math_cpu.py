@@ -80,3 +80,22 @@ def test_xyzz_group_law_all_cases(mc, group):
             assert frm(call(mc, fn, 1, lim(A), lim(B), nout=nl)) == cur.add(A, B)
             assert frm(call(mc, fn, 2, lim(A), lim(B), nout=nl)) == cur.add(A, A)
             assert frm(call(mc, fn, 3, lim(A), lim(B), nout=nl)) == cur.add(A, cur.neg(B))
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_host_scalar_multiplications_agree_with_the_oracle(mc, group):
+    """the prover's host-side multiplications (round 4): 4-bit windows for s * A and r * B1, a fixed-base table of 32 x 255 multiples for the
+    multiples of delta -- against the bit-by-bit loop and the oracle's k * P, for scalars with zero bytes, all-ones bytes, 0, 1 and r - 1"""
+    g = load_golden("curve.json")[group]
+    if group == "g1":
+        cur, lim, frm, dec, nl, fn = o.G1, g1_limbs, o.g1_from_limbs, dec1, 12, "chk_hg1_mul"
+    else:
+        cur, lim, frm, dec, nl, fn = o.G2, g2_limbs, o.g2_from_limbs, dec2, 24, "chk_hg2_mul"
+    P = dec(g["P1"])
+    gen = o.splitmix64(1234)
+    ks = [0, 1, 2, 255, 256, o.R - 1, (1 << 255) - 19 - o.R, 0xFF00FF00FF00FF00FF00FF00FF00FF00, 0x0100000000000000000000000000000000000000000000000000000000000001]
+    ks += [o.rand_fr(gen) for _ in range(3)]
+    for k in ks:
+        want = cur.mul(P, k % o.R) if k % o.R else None
+        for mode in (0, 1, 2):
+            assert frm(call(mc, fn, mode, lim(P), L(k, 4), nout=nl)) == want, (hex(k), mode)

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "../../include/vsp.h"
+#include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "curve.h"
@@ -182,6 +184,12 @@ struct vsp_pk {
     vsp::Affine<vsp::HFp> alpha_g1, beta_g1, delta_g1;     // host, Montgomery
     vsp::Affine<vsp::HFp2> beta_g2, delta_g2;
     const vsp_bases *A = nullptr, *B1 = nullptr, *B2 = nullptr, *H = nullptr, *L = nullptr;
+    // every proof multiplies delta (G1: by r, s, r s; G2: by s): fixed-base tables of d 2^(8 w) delta, d = 1..255, w = 0..31, built by the
+    // first proof over this key (prover.hip delta_tables; contexts on several threads share a key: built once, under the mutex)
+    mutable std::mutex tab_mu;
+    mutable std::atomic<bool> tab_ready{false};
+    mutable std::vector<vsp::XYZZ<vsp::HFp>> tab1;
+    mutable std::vector<vsp::XYZZ<vsp::HFp2>> tab2;
 };
 
 namespace vsp {

@@ -10,6 +10,7 @@
 // Generic over the field type F (device: Fp / Fp2 with 32-bit limbs; host: HFp / HFp2).
 #pragma once
 #include "field.h"
+#include <vector>
 
 namespace vsp {
 
@@ -150,6 +151,40 @@ template <class F> VSP_HD XYZZ<F> xyzz_mul_scalar(const XYZZ<F> &p, const uint64
     for (int i = nbits - 1; i >= 0; i--) {
         acc = xyzz_dbl(acc);
         if ((k[i >> 6] >> (i & 63)) & 1) xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+// the same with 4-bit windows (host side: the prover's s * A and r * B1): 14 additions for the table, then 4 doublings and at most one
+// addition per window -- 255 + 78 group operations instead of 255 + ~127
+template <class F> VSP_HD XYZZ<F> xyzz_mul_scalar_w4(const XYZZ<F> &p, const uint64_t *k) {
+    XYZZ<F> tab[16];
+    tab[0] = XYZZ<F>::inf(); tab[1] = p;
+    for (int d = 2; d < 16; d++) { tab[d] = tab[d - 1]; if (d & 1) xyzz_add(tab[d], p); else tab[d] = xyzz_dbl(tab[d >> 1]); }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 63; w >= 0; w--) {
+        if (w != 63) { acc = xyzz_dbl(acc); acc = xyzz_dbl(acc); acc = xyzz_dbl(acc); acc = xyzz_dbl(acc); }
+        const unsigned d = (unsigned)(k[w >> 4] >> ((w & 15) * 4)) & 15u;
+        if (d) xyzz_add(acc, tab[d]);
+    }
+    return acc;
+}
+// fixed base: tab[255 w + d - 1] = d 2^(8 w) P for d = 1..255, w = 0..31 (build: 255 additions per window, 8 doublings between windows);
+// k * P = the sum of one entry per non-zero byte of k: at most 32 additions
+template <class F> inline void xyzz_fixed_base_table(const XYZZ<F> &p, std::vector<XYZZ<F>> &tab) {
+    tab.resize(32 * 255);
+    XYZZ<F> base = p;
+    for (int w = 0; w < 32; w++) {
+        XYZZ<F> cur = base;
+        for (int d = 1; d <= 255; d++) { tab[(size_t)255 * w + d - 1] = cur; if (d < 255) xyzz_add(cur, base); }
+        for (int i = 0; i < 8; i++) base = xyzz_dbl(base);
+    }
+}
+template <class F> inline XYZZ<F> xyzz_mul_fixed(const std::vector<XYZZ<F>> &tab, const uint64_t *k) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = 0; w < 32; w++) {
+        const unsigned d = (unsigned)(k[w >> 3] >> ((w & 7) * 8)) & 255u;
+        if (d) xyzz_add(acc, tab[(size_t)255 * w + d - 1]);
     }
     return acc;
 }

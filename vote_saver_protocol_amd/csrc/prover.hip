@@ -130,6 +130,24 @@ vsp_pk *vsp_pk_create(vsp_ctx *ctx, const uint64_t alpha_g1[12], const uint64_t 
     return pk;
 }
 void vsp_pk_free(vsp_ctx *, vsp_pk *pk) { delete pk; }
+}  // extern "C"
+namespace vsp {
+// the fixed-base tables of delta (common.h vsp_pk): built by the first proof over the key, 32 x 255 additions per group (~5 ms G1, ~15 ms G2);
+// option "prove_fixed_base" = 0 keeps the double-and-add multiplications of rounds 1-3
+static bool delta_tables(vsp_ctx *ctx, const vsp_pk *pk) {
+    { auto it = ctx->opts.find("prove_fixed_base"); if (it != ctx->opts.end() && it->second == 0) return false; }
+    if (pk->tab_ready.load(std::memory_order_acquire)) return true;
+    std::lock_guard<std::mutex> lock(pk->tab_mu);
+    if (!pk->tab_ready.load(std::memory_order_relaxed)) {
+        std::thread t2([&]() { xyzz_fixed_base_table(xyzz_from_affine(pk->delta_g2), pk->tab2); });
+        xyzz_fixed_base_table(xyzz_from_affine(pk->delta_g1), pk->tab1);
+        t2.join();
+        pk->tab_ready.store(true, std::memory_order_release);
+    }
+    return true;
+}
+}  // namespace vsp
+extern "C" {
 
 // the witness as the caller hands it over: plain (num_vars x 4 canonical words), or packed (vsp_witness_pack)
 struct WitnessSrc { const uint64_t *plain; const uint64_t *class_words; const uint32_t *word_offsets; const uint64_t *dense; size_t n_dense; };
@@ -387,12 +405,13 @@ static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24
     XYZZ<HFp2> s_delta2;
     long hthreads = 1; { auto it = ctx->opts.find("prove_host_threads"); if (it != ctx->opts.end()) hthreads = it->second; }
     const unsigned T = hthreads ? 8u : 1u;
+    const bool fixed = delta_tables(ctx, pk);                 // (round 4: at most 32 additions per multiple of delta instead of 255 doublings + ~127 additions)
     host_parallel_for(5, [&](size_t j) {
-        if (j == 0) s_delta2 = xyzz_mul_scalar(dj2, s, 255);                 // the G2 one is the longest: first
-        else if (j == 1) r_delta = xyzz_mul_scalar(dj, r, 255);
-        else if (j == 2) s_delta = xyzz_mul_scalar(dj, s, 255);
-        else if (j == 3) neg_rs_delta = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
-        else if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc, 255);
+        if (j == 0) s_delta2 = fixed ? xyzz_mul_fixed(pk->tab2, s) : xyzz_mul_scalar(dj2, s, 255);                 // the G2 one is the longest: first
+        else if (j == 1) r_delta = fixed ? xyzz_mul_fixed(pk->tab1, r) : xyzz_mul_scalar(dj, r, 255);
+        else if (j == 2) s_delta = fixed ? xyzz_mul_fixed(pk->tab1, s) : xyzz_mul_scalar(dj, s, 255);
+        else if (j == 3) neg_rs_delta = xyzz_neg(fixed ? xyzz_mul_fixed(pk->tab1, rs4) : xyzz_mul_scalar(dj, rs4, 255));
+        else if (saver_P1 && saver_r_enc) saver = xyzz_mul_scalar_w4(xyzz_from_affine(host_load_g1(saver_P1)), saver_r_enc);
     }, T);
     if (overlap && *overlap) (*overlap)();
     lap("prove_host_overlap_ms");
@@ -408,11 +427,11 @@ static int prove_finish_impl(vsp_ctx *ctx, uint64_t A_out[12], uint64_t B_out[24
     int rc = VSP_OK; bool empty = false;
     if ((rc = msm_g1_finish_wait(ctx, 1, &empty)) == VSP_OK) {
         const bool e = empty;
-        run([&, e]() { if (!e) msm_g1_fold(ctx, 1, &eA); gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta); s_gA = xyzz_mul_scalar(gA, s, 255); });
+        run([&, e]() { if (!e) msm_g1_fold(ctx, 1, &eA); gA = eA; xyzz_madd(gA, pk->alpha_g1); xyzz_add(gA, r_delta); s_gA = xyzz_mul_scalar_w4(gA, s); });
     }
     if (rc == VSP_OK && (rc = msm_g1_finish_wait(ctx, 2, &empty)) == VSP_OK) {
         const bool e = empty;
-        run([&, e]() { if (!e) msm_g1_fold(ctx, 2, &eB1); gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta); r_gB1 = xyzz_mul_scalar(gB1, r, 255); });
+        run([&, e]() { if (!e) msm_g1_fold(ctx, 2, &eB1); gB1 = eB1; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta); r_gB1 = xyzz_mul_scalar_w4(gB1, r); });
     }
     if (rc == VSP_OK && (rc = msm_g1_finish_wait(ctx, 4, &empty)) == VSP_OK) {
         const bool e = empty;
@@ -512,12 +531,19 @@ static int prove_batch_finish_impl(vsp_ctx *ctx, const vsp_pk *pk, size_t K, con
     XYZZ<HFp2> dj2 = xyzz_from_affine(pk->delta_g2);
     std::vector<XYZZ<HFp>> r_delta(K), s_delta(K), neg_rs_delta(K);
     std::vector<XYZZ<HFp2>> s_delta2(K);
+    const bool fixed = delta_tables(ctx, pk);
     host_parallel_for(K, [&](size_t k) {
         const uint64_t *rk = r + 4 * k, *sk = s + 4 * k;
         uint64_t rs4[4]; host_store_canon(rs4, mul(host_load_canon<HFr>(rk), host_load_canon<HFr>(sk)));
-        r_delta[k] = xyzz_mul_scalar(dj, rk, 255); s_delta[k] = xyzz_mul_scalar(dj, sk, 255);
-        neg_rs_delta[k] = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
-        s_delta2[k] = xyzz_mul_scalar(dj2, sk, 255);
+        if (fixed) {
+            r_delta[k] = xyzz_mul_fixed(pk->tab1, rk); s_delta[k] = xyzz_mul_fixed(pk->tab1, sk);
+            neg_rs_delta[k] = xyzz_neg(xyzz_mul_fixed(pk->tab1, rs4));
+            s_delta2[k] = xyzz_mul_fixed(pk->tab2, sk);
+        } else {
+            r_delta[k] = xyzz_mul_scalar(dj, rk, 255); s_delta[k] = xyzz_mul_scalar(dj, sk, 255);
+            neg_rs_delta[k] = xyzz_neg(xyzz_mul_scalar(dj, rs4, 255));
+            s_delta2[k] = xyzz_mul_scalar(dj2, sk, 255);
+        }
     });
     lap("prove_batch_delta_ms");
     std::vector<XYZZ<HFp>> eA(K), eB1(K), eH(K), eL(K);
@@ -531,9 +557,9 @@ static int prove_batch_finish_impl(vsp_ctx *ctx, const vsp_pk *pk, size_t K, con
     std::vector<XYZZ<HFp>> gA(K), s_gA(K), r_gB1(K);
     host_parallel_for(K, [&](size_t k) {
         gA[k] = eA[k]; xyzz_madd(gA[k], pk->alpha_g1); xyzz_add(gA[k], r_delta[k]);
-        s_gA[k] = xyzz_mul_scalar(gA[k], s + 4 * k, 255);
+        s_gA[k] = xyzz_mul_scalar_w4(gA[k], s + 4 * k);
         XYZZ<HFp> gB1 = eB1[k]; xyzz_madd(gB1, pk->beta_g1); xyzz_add(gB1, s_delta[k]);
-        r_gB1[k] = xyzz_mul_scalar(gB1, r + 4 * k, 255);
+        r_gB1[k] = xyzz_mul_scalar_w4(gB1, r + 4 * k);
     });
     lap("prove_batch_sA_rB1_ms");
     VSP_TRY(msm_g1_finish_batch(ctx, 0, eH.data(), (unsigned)K));
