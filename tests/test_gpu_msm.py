@@ -694,6 +694,18 @@ def test_batch_of_scalar_vectors_over_one_set_of_bases(ctx, cref, group, n, K, k
                 exp = msm(bases[first:first + cnt], vecs[k, :cnt], mixed=True)
                 assert np.array_equal(got[k], exp), (group, n, K, glv, first, k)
                 assert bool(inf[k]) == (not exp.any())
+        # the same batch over the table of window multiples (end of round 4): ONE bucket set per vector, slices of the table per window
+        if n >= 257:
+            for wb in (12, 16) if n >= 2000 else (9,):
+                B.precompute(wb, split=bool(glv))
+                for first in (0, 3):
+                    cnt = n if first == 0 else n - 1
+                    got, inf = B.msm_batch(d_s, K, n=cnt, first=first, stride=stride)
+                    for k in range(K):
+                        exp = msm(bases[first:first + cnt], vecs[k, :cnt], mixed=True)
+                        assert np.array_equal(got[k], exp), (group, n, K, glv, first, k, "table", wb)
+                        assert bool(inf[k]) == (not exp.any())
+                B.free(); B = ctx.upload_bases(bases, group)
         B.free()
     ctx.set_option("msm_glv", 1)
     ctx.dfree(d_s)

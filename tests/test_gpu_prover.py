@@ -241,8 +241,8 @@ def test_prove_in_two_halves_and_from_a_packed_witness(cref):
 @pytest.mark.parametrize("nc,ni,K", [(10, 2, 3), (300, 5, 4), (2000, 30, 8), (5000, 3, 2)])
 def test_batch_of_proofs_is_byte_identical_to_single_proofs_and_the_oracle(ctx, cref, nc, ni, K):
     """vsp_groth16_prove_batch (round 4): K witnesses of one constraint system proved in one pass over a plain key -- every proof equals the
-    oracle's r1cs_gg_ppzksnark proof and vsp_groth16_prove's 192 bytes for the same (witness, r, s), under K different (r, s); a key with
-    tables of window multiples is refused."""
+    oracle's r1cs_gg_ppzksnark proof and vsp_groth16_prove's 192 bytes for the same (witness, r, s), under K different (r, s); over a key with
+    tables of window multiples too."""
     cs, wit0, kp, dcs, pk, q, r0, s0 = build(ctx, cref, nc, ni, seed=nc + K)
     gen = o.splitmix64(7 * nc + K)
     wits, rs, ss = [wit0], [r0], [s0]
@@ -256,10 +256,15 @@ def test_batch_of_proofs_is_byte_identical_to_single_proofs_and_the_oracle(ctx, 
         assert np.array_equal(A[k], eA) and np.array_equal(B[k], eB) and np.array_equal(Cc[k], eC), k
         sA, sB, sC, sproof = v.groth16_prove(ctx, dcs, pk, wits[k], rs[k], ss[k])
         assert proofs[k] == sproof and np.array_equal(A[k], sA), k
-    # a key with tables of window multiples is refused, the context stays usable
-    q[0].precompute(12)
-    with pytest.raises(v.VspError):
-        v.groth16_prove_batch(ctx, dcs, pk, W, R, S)
+    # a key with tables of window multiples (end of round 4: one bucket set per witness and query): the same proofs; refused with msm_batch_tables = 0
+    for x in q: x.precompute(12)
+    assert v.groth16_prove_batch(ctx, dcs, pk, W, R, S)[3] == proofs
+    ctx.set_option("msm_batch_tables", 0)
+    try:
+        with pytest.raises(v.VspError):
+            v.groth16_prove_batch(ctx, dcs, pk, W, R, S)
+    finally:
+        ctx.set_option("msm_batch_tables", 1)
     assert v.groth16_prove(ctx, dcs, pk, wits[0], rs[0], ss[0])[3] == proofs[0]
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
 

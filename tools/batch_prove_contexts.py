@@ -8,11 +8,12 @@ import vote_saver_protocol_amd as v
 lg = int(os.environ.get("LOG_M", "16")); reps = int(os.environ.get("REPS", "8"))
 ni = 30; nc = (1 << lg) - ni - 2
 ctx = v.Context(0)
+if os.environ.get("PRE_WINDOW"): ctx.set_option("generate_precompute_window", int(os.environ["PRE_WINDOW"]))
 gen = o.splitmix64(16)
 cs, wit = cref.R1CS.synth(nc, ni, 40, ballot=(25, 3))
 tox = np.array([o.int_to_limbs(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
 dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
-kp = v.Keypair(ctx, dcs, tox, precompute=0)
+kp = v.Keypair(ctx, dcs, tox, precompute=int(os.environ.get("PRE", "0")))
 ctxs = [ctx] + [v.Context(0) for _ in range(3)]
 out = []
 for K in [int(x) for x in os.environ.get("KS", "8,16,32").split(",")]:

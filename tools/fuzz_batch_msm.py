@@ -11,7 +11,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ctx = v.Context(0)
 pool1 = cref.g1_batch_mul_gen(rand_fr_array(20000, seed=3000 + seed)); pool2 = cref.g2_batch_mul_gen(rand_fr_array(2500, seed=4000 + seed))
-t0 = time.time(); it = 0; vecs_done = 0; last = time.time()
+t0 = time.time(); it = 0; vecs_done = 0; tables = 0; last = time.time()
 while time.time() - t0 < budget:
     it += 1
     if time.time() - last > 60:
@@ -41,13 +41,18 @@ while time.time() - t0 < budget:
     ctx.set_option("msm_glv", int(rng.choice([1, 1, 0, 2])))
     ctx.set_option("msm_split", int(rng.choice([0, 0, 16, 64])))
     B = ctx.upload_bases(bases, group); d_s = ctx.to_device(vecs.reshape(-1, 4))
+    table = None
+    if rng.random() < 0.35:                                    # over a table of window multiples: one bucket set per vector
+        table = (int(rng.integers(8, 17)), bool(rng.random() < 0.5))
+        B.precompute(table[0], split=table[1])
     first = int(rng.integers(0, n)) if rng.random() < 0.3 else 0
     got, inf = B.msm_batch(d_s + 32 * first, K, n=n - first, first=first, stride=stride)
     msm = cref.msm_g1 if group == 1 else cref.msm_g2
     for k in range(K):
         exp = msm(bases[first:], vecs[k, first:n], mixed=True)
         if not np.array_equal(got[k], exp):
-            print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, K=K, k=k, first=first)); sys.exit(1)
+            print("MISMATCH", dict(it=it, seed=seed, group=group, n=n, K=K, k=k, first=first, table=table)); sys.exit(1)
     vecs_done += K
     B.free(); ctx.dfree(d_s)
-print("batch fuzz ok: %d batches, %d vectors in %.0f s" % (it, vecs_done, time.time() - t0))
+    tables = tables + 1 if table else tables
+print("batch fuzz ok: %d batches (%d over tables of window multiples), %d vectors in %.0f s" % (it, tables, vecs_done, time.time() - t0))

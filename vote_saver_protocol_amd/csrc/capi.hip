@@ -505,7 +505,13 @@ int launch_on_bases(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t 
 // the same for a batch of scalar vectors (vector k at d_scalars + k * stride) over PLAIN resident bases: one launch, one result per vector
 int launch_on_bases_batch(vsp_ctx *ctx, unsigned slot, const vsp_bases *bases, size_t first, size_t n, const Fr *d_scalars, unsigned batch, size_t stride, bool dense, int plan_from_slot) {
     if (slot < VSP_MSM_SLOTS) ctx->slot_group[slot] = bases->group;
-    if (bases->pre_c) return set_error(ctx, VSP_ERR_UNSUPPORTED, "msm: a batch runs over plain bases (no table of window multiples)");
+    if (bases->pre_c) {                                       // the table of window multiples: ONE bucket set per vector (round 4, last hours)
+        long allow = 1; { auto it = ctx->opts.find("msm_batch_tables"); if (it != ctx->opts.end()) allow = it->second; }
+        if (!allow || bases->pre_c > 16) return set_error(ctx, VSP_ERR_UNSUPPORTED, "msm: a batch over this table of window multiples is not supported (plain bases, or windows of at most 16 bits)");
+        MsmPre pre{bases->n, first, bases->pre_c, bases->d28, bases->glv};
+        if (bases->group == 1) return msm_g1_launch_batch(ctx, slot, (const G1Affine *)bases->d, d_scalars, n, batch, stride, dense, nullptr, bases->glv, plan_from_slot, &pre);
+        return msm_g2_launch_batch(ctx, slot, (const G2Affine *)bases->d, d_scalars, n, batch, stride, dense, nullptr, bases->glv, plan_from_slot, &pre);
+    }
     if (bases->group == 1)
         return msm_g1_launch_batch(ctx, slot, (const G1Affine *)bases->d + first, d_scalars, n, batch, stride, dense,
                                    bases->d28 ? (const char *)bases->d28 + first * sizeof(Affine28) * (bases->glv ? 2 : 1) : nullptr, bases->glv, plan_from_slot);

@@ -260,9 +260,9 @@ int msm_g2_launch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr
                   const void *plain_table28 = nullptr, bool glv = false);
 int msm_g2_finish(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out);
 // a batch of scalar vectors over one set of PLAIN bases (MsmGeom.K): vector k at d_scalars + k * stride; one result per vector
-int msm_g1_launch_batch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1);
+int msm_g1_launch_batch(vsp_ctx *ctx, unsigned slot, const G1Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1, const MsmPre *pre = nullptr);
 int msm_g1_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp> *out, unsigned batch);
-int msm_g2_launch_batch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1);
+int msm_g2_launch_batch(vsp_ctx *ctx, unsigned slot, const G2Affine *d_bases, const Fr *d_scalars, size_t n, unsigned batch, size_t stride, bool dense, const void *plain_table28, bool glv, int plan_from_slot = -1, const MsmPre *pre = nullptr);
 int msm_g2_finish_batch(vsp_ctx *ctx, unsigned slot, XYZZ<HFp2> *out, unsigned batch);
 // a finish in two halves: the wait (context state: caller's thread) and the fold of the window results (pure host arithmetic over the slot: any thread)
 int msm_g1_finish_wait(vsp_ctx *ctx, unsigned slot, bool *empty);

@@ -141,7 +141,8 @@ vsp_keypair *vsp_groth16_generate(vsp_ctx *ctx, const vsp_r1cs *cs, const uint64
         // small beside 2^20 * 16 additions, and the plain 128 MB table is read out of the Infinity Cache where the 2 GB table of window
         // multiples misses it (2^20 constraints: 9.15 ms per proof against 9.45 with H precomputed too, and 2 GB less key memory)
         const bool pre_this = i < 5 && (((precompute & 1) && i != 3) || ((precompute >> (i + 1)) & 1));
-        if (pre_this && vsp_bases_precompute(ctx, kp->q[i], 0) != VSP_OK) return fail(nullptr);
+        long pre_window = 0; { auto itw = ctx->opts.find("generate_precompute_window"); if (itw != ctx->opts.end() && itw->second >= 8 && itw->second <= 22) pre_window = itw->second; }
+        if (pre_this && vsp_bases_precompute(ctx, kp->q[i], (unsigned)pre_window) != VSP_OK) return fail(nullptr);      // (0: by the query's size)
     }
     // single elements on the host
     Affine<HFp> g1 = host_load_g1(G1_GEN_L); Affine<HFp2> g2 = host_load_g2(G2_GEN_L);

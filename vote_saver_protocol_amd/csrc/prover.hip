@@ -480,8 +480,8 @@ static int prove_batch_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_p
     const size_t nv = cs->num_vars, ni = cs->num_inputs, nc = cs->num_constraints, m = cs->dom.m, zs = nv + 1;
     if (pk->A->n != nv + 1 || pk->B1->n != nv + 1 || pk->B2->n != nv + 1 || pk->H->n + 1 != m || pk->L->n != nv - ni)
         return set_error(ctx, VSP_ERR_ARG, "prove: proving key does not match the constraint system");
-    if (pk->A->pre_c || pk->B1->pre_c || pk->B2->pre_c || pk->H->pre_c || pk->L->pre_c)
-        return set_error(ctx, VSP_ERR_UNSUPPORTED, "prove_batch: needs a plain key (no tables of window multiples)");
+    // (a key with tables of window multiples: one bucket set per witness and query, windows of 16 bits -- worth it where the tables are small, i.e. at
+    // the real circuit's size; option "msm_batch_tables" = 0 refuses such keys as rounds before the end of round 4 did)
     VSP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -512,7 +512,8 @@ static int prove_batch_launch_impl(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_p
     VSP_TRY(launch_on_bases_batch(ctx, 1, pk->A, 0, nv + 1, dz, (unsigned)K, zs, false));
     // A, B1 and B2 multiply by the same K witness vectors: one digit sort and bucket plan (A's) serves the three (option "prove_batch_share_plan")
     long share = 1; { auto it = ctx->opts.find("prove_batch_share_plan"); if (it != ctx->opts.end()) share = it->second; }
-    const bool same_shape = pk->A->glv == pk->B1->glv && pk->A->glv == pk->B2->glv && (pk->A->d28 != nullptr) == (pk->B1->d28 != nullptr) && (pk->A->d28 != nullptr) == (pk->B2->d28 != nullptr);
+    const bool same_shape = pk->A->glv == pk->B1->glv && pk->A->glv == pk->B2->glv && (pk->A->d28 != nullptr) == (pk->B1->d28 != nullptr) && (pk->A->d28 != nullptr) == (pk->B2->d28 != nullptr) &&
+                            pk->A->pre_c == pk->B1->pre_c && pk->A->pre_c == pk->B2->pre_c && pk->A->n == pk->B1->n && pk->A->n == pk->B2->n;
     const int from_a = share && same_shape && nv + 1 > 0 ? 1 : -1;
     VSP_TRY(launch_on_bases_batch(ctx, 3, pk->B2, 0, nv + 1, dz, (unsigned)K, zs, false, from_a));
     VSP_TRY(launch_on_bases_batch(ctx, 2, pk->B1, 0, nv + 1, dz, (unsigned)K, zs, false, from_a));
