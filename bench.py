@@ -197,6 +197,26 @@ def bench_prove_small(ctx, v, cref, o, log_m=16, precompute=True):
                 v.groth16_prove_batch_launch(c, dcs, kpp.pk, W, R, S)
         multi["one_thread_two_batches_of_32_in_flight"] = total * K / (time.perf_counter() - t0)
         multi["one_thread_every_proof_equals_the_single_call"] = bool(same_b)
+        # the same ring over a key whose FIVE queries carry 14-bit tables of window multiples (small at this size): one bucket set per witness
+        # and query instead of one per window -- only where the tables are cheap (the real circuit's size, not 2^20)
+        if log_m <= 17:
+            ctx.set_option("generate_precompute_window", 14)
+            kpt = v.Keypair(ctx, dcs, tox, precompute=17)
+            ctx.set_option("generate_precompute_window", 0)
+            ring3, same_t = ctxb[:3], True
+            for c in ring3:
+                v.groth16_prove_batch(c, dcs, kpt.pk, W, R, S)
+            t0 = time.perf_counter()
+            for i in range(total + 3):
+                c = ring3[i % 3]
+                if i >= 3:
+                    same_t = same_t and all(p == single[3] for p in v.groth16_prove_batch_finish(c)[3])
+                if i < total:
+                    v.groth16_prove_batch_launch(c, dcs, kpt.pk, W, R, S)
+            multi["one_thread_three_batches_of_32_in_flight_table_key"] = total * K / (time.perf_counter() - t0)
+            multi["table_key_every_proof_equals_the_single_call"] = bool(same_t)
+            multi["table_key_bytes"] = int(kpt.device_bytes())
+            kpt.free()
         for c in ctxb[1:]:
             c.close()
         out[f"prove_2p{log_m}_batched_multi_context_proofs_per_s"] = multi

@@ -79,6 +79,7 @@ void vsp_stats_reset(vsp_ctx *ctx);
  * 12 x 32-bit kernel runs), "prove_plan_first" (1: the witness vectors' digit sorts are queued before witness_map),
  * "prove_host_threads" (default 1: the prover's host steps -- the four multiples of delta, the Horner chain over each multi-exponentiation's
  * window results, s*A and r*B1 -- run on host threads of their own inside the wait for the GPU; 0: on the calling thread, one after the other),
+ * "generate_precompute_window" (8..22; 0 = by the query's size: the window of the tables vsp_groth16_generate builds when `precompute` asks for them),
  * "prove_fixed_base" (default 1: the multiples of delta every proof needs come from fixed-base tables of 32 x 255 multiples per group,
  * built on the host by the first proof over a key -- at most 32 additions per multiple; 0: double-and-add),
  * "prove_batch_share_plan" (default 1: in vsp_groth16_prove_batch the B1 and B2 multi-exponentiations take A's digit sort and bucket plan --
@@ -274,8 +275,11 @@ int vsp_groth16_prove(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const 
  * outputs count x 12 / 24 / 12 words and count x 192 bytes (any may be NULL).  Proof k is byte-identical to vsp_groth16_prove(witness_k,
  * r_k, s_k).  Proofs of a small circuit (2^15..2^16 constraints) are bound by the latency of their dependent kernel chains, not by work:
  * proved together, the same launches run `count` times as wide -- one witness_map over 3 x count transforms, every multi-exponentiation
- * once over `count` scalar vectors.  Needs a PLAIN key (vsp_groth16_generate with precompute = 0: 10 x less memory than the tables of
- * window multiples, which buy a single proof ~5 %); VSP_ERR_UNSUPPORTED otherwise.  No SAVER addend (vsp_saver_encrypt proves one vote). */
+ * once over `count` scalar vectors.  Over a PLAIN key (vsp_groth16_generate with precompute = 0) every (witness, window) pair has its own
+ * bucket set; over a key with tables of window multiples (windows of at most 16 bits) every witness has ONE per query, which is ~12 %
+ * faster where the tables are small -- 2^16 constraints, precompute = 17 (all five queries), option "generate_precompute_window" = 14:
+ * 1.7 GB -- and no use at 2^20 (19 GB).  Option "msm_batch_tables" = 0 refuses table keys (VSP_ERR_UNSUPPORTED), as the first version did.
+ * No SAVER addend (vsp_saver_encrypt proves one vote). */
 int vsp_groth16_prove_batch(vsp_ctx *ctx, const vsp_r1cs *cs, const vsp_pk *pk, const uint64_t *witnesses, size_t count,
                             const uint64_t *r, const uint64_t *s, uint64_t *A_out, uint64_t *B_out, uint64_t *C_out, uint8_t *proofs_out);
 /* The batch in two halves, as vsp_groth16_prove_launch / _finish below: launch copies the witnesses, r and s, queues every kernel of the
