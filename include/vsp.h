@@ -168,7 +168,9 @@ int vsp_msm_resident(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t 
  * d_scalars + 32 * k * stride bytes (stride >= n, in scalars), out_affine[k] / out_is_inf[k] = sum_i scalars_k[i] * bases[first + i].
  * One digit sort, one bucket accumulation and one bucket reduction serve all vectors (separate buckets per vector, the same base rows):
  * what a prover of MANY small statements over one key needs -- small multi-exponentiations are bound by the latency of their dependent
- * chains, not by work, and a batch is as wide as its vectors together at the latency of one.  Plain bases only (no window multiples). */
+ * chains, not by work, and a batch is as wide as its vectors together at the latency of one.  Plain bases: a bucket set per (vector, window);
+ * bases with a table of window multiples (windows of at most 16 bits): ONE bucket set per vector -- fewer, larger windows, worth it where
+ * the table is small (VSP_ERR_UNSUPPORTED for wider windows, or with option "msm_batch_tables" = 0). */
 int vsp_msm_resident_batch(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n, const void *d_scalars, size_t batch, size_t stride,
                            uint64_t *out_affine /* batch x 12 or 24 */, int *out_is_inf /* batch, may be NULL */);
 int vsp_msm_resident_jacobian(vsp_ctx *ctx, const vsp_bases *bases, size_t first, size_t n,
