@@ -200,9 +200,7 @@ def bench_prove_small(ctx, v, cref, o, log_m=16, precompute=True):
         # the same ring over a key whose FIVE queries carry 14-bit tables of window multiples (small at this size): one bucket set per witness
         # and query instead of one per window -- only where the tables are cheap (the real circuit's size, not 2^20)
         if log_m <= 17:
-            ctx.set_option("generate_precompute_window", 14)
-            kpt = v.Keypair(ctx, dcs, tox, precompute=17)
-            ctx.set_option("generate_precompute_window", 0)
+            kpt = v.Keypair(ctx, dcs, tox, precompute=17, precompute_window=14)
             ring3, same_t = ctxb[:3], True
             for c in ring3:
                 v.groth16_prove_batch(c, dcs, kpt.pk, W, R, S)

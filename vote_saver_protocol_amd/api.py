@@ -413,11 +413,20 @@ KEY_PARTS = {"A_query": (0, 12), "B_query_g1": (1, 12), "B_query_g2": (2, 24), "
 class Keypair:
     """zk::generate<proof_system>(constraint_system) on the GPU with explicit toxic waste [5,4] = (t, alpha, beta, gamma, delta)."""
 
-    def __init__(self, ctx, cs, toxic, precompute=False, _handle=None):
+    def __init__(self, ctx, cs, toxic, precompute=False, precompute_window=0, _handle=None):
+        """precompute: False / 0 = a plain key; True / 1 = tables of window multiples on A, B(G1), B(G2), L; else a bit mask (vsp.h; 17 = all
+        five queries).  precompute_window: the tables' window in bits (0 = by the query's size).  For batched proving at the real circuit's
+        size (2^15..2^16 constraints): precompute=17, precompute_window=14."""
         self.ctx = ctx
         if _handle is None:
             toxic = _u64(toxic).reshape(20)
-            _handle = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(precompute))      # True = 1 = every query; else a bit mask (vsp.h)
+            if precompute_window:
+                ctx.set_option("generate_precompute_window", int(precompute_window))
+            try:
+                _handle = ctx.lib.vsp_groth16_generate(ctx.h, cs.h, _ptr(toxic), int(precompute))
+            finally:
+                if precompute_window:
+                    ctx.set_option("generate_precompute_window", 0)
             if not _handle:
                 raise VspError("groth16_generate failed: " + ctx.last_error())
         self.h = _handle
