@@ -378,3 +378,28 @@ def test_batch_prover_with_and_without_the_shared_digit_sort(ctx, cref):
     finally:
         ctx.set_option("prove_batch_share_plan", 1); ctx.set_option("msm_dimbits", -1)
     pk.free(); dcs.free(); [x.free() for x in q]; kp.free(); cs.free()
+
+
+def test_batch_over_a_generated_key_with_tables_on_all_five_queries(ctx, cref):
+    """the configuration DESIGN.md 3.3b recommends for batched proving at the real circuit's size: vsp_groth16_generate with tables of window
+    multiples on all five queries (precompute = 17) and a chosen window -- every proof of a batch against the oracle's prover, and the two
+    halves over the same key"""
+    nc, ni, K = 2500, 4, 5
+    gen = o.splitmix64(171)
+    cs, wit = cref.R1CS.synth(nc, ni, 171)
+    tox = np.array([L(o.rand_fr(gen), 4) for _ in range(5)], dtype=np.uint64)
+    dcs = v.R1CS(ctx, nc, ni, cs.num_vars, *cs.export())
+    ref = cref.Keypair(cs, tox)
+    W = np.ascontiguousarray(np.broadcast_to(wit, (K,) + wit.shape))
+    R = np.stack([L(o.rand_fr(gen), 4) for _ in range(K)]); S = np.stack([L(o.rand_fr(gen), 4) for _ in range(K)])
+    for window in (9, 14):
+        kp = v.Keypair(ctx, dcs, tox, precompute=17, precompute_window=window)
+        A, B, Cc, proofs = v.groth16_prove_batch(ctx, dcs, kp.pk, W, R, S)
+        for k in range(K):
+            eA, eB, eC = ref.prove(wit, R[k], S[k])
+            assert np.array_equal(A[k], eA) and np.array_equal(B[k], eB) and np.array_equal(Cc[k], eC), (window, k)
+        v.groth16_prove_batch_launch(ctx, dcs, kp.pk, W, R, S)
+        assert v.groth16_prove_batch_finish(ctx)[3] == proofs
+        assert v.groth16_prove(ctx, dcs, kp.pk, wit, R[0], S[0])[3] == proofs[0]
+        kp.free()
+    dcs.free(); ref.free(); cs.free()
