@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
     pa, pb, pc, _ = v.groth16_prove(ctx, dcs, kp.pk, wit, r, s_, saver_P1=P1, saver_r_enc=renc)
     ea, eb, ec = ref.prove(wit, r, s_, P1=P1, r_enc=renc)
     ok = ok and np.array_equal(pa, ea) and np.array_equal(pb, eb) and np.array_equal(pc, ec)
-    if ok and not pre and rng.random() < 0.6:                 # the same statement(s) through the batch prover (plain keys; basic and step domains)
+    if ok and rng.random() < 0.6:                             # the same statement(s) through the batch prover (plain and table keys; basic and step domains)
         K = int(rng.integers(1, 7))
         R = rand_fr_array(K, seed=s + 4); S = rand_fr_array(K, seed=s + 5)
         if rng.random() < 0.5:
@@ -55,6 +55,7 @@ while time.time() - t0 < budget:
             xa, xb, xc = ref.prove(wit, R[k], S[k])
             ok = ok and np.array_equal(bA[k], xa) and np.array_equal(bB[k], xb) and np.array_equal(bC[k], xc)
         kinds["batched"] = kinds.get("batched", 0) + 1
+        if pre: kinds["batched_table_key"] = kinds.get("batched_table_key", 0) + 1
     kp.free(); dcs.free(); ref.free(); cs.free()
     if not ok:
         print("MISMATCH", dict(it=it, seed=seed, nc=nc, ni=ni, synth_seed=s, pre=pre, saver=saver)); sys.exit(1)
